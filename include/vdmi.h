@@ -1,0 +1,209 @@
+/*
+ * vdmi — MI355X (gfx950) kernels for the denoising hot path of kasjfksj/video-diffusion:
+ * the Unet3D forward called at every step of GaussianDiffusion.p_sample_loop, and the
+ * DDPM posterior update around it.
+ *
+ * The reference is pure Python and has no FFI of its own; the seam it offers is the
+ * `denoise_fn` callable and the nn.Module tree.  Every entry point below therefore cites
+ * the reference *arithmetic* it replaces (file:line under the reference repository,
+ * vdp.py = video_diffusion_pytorch/video_diffusion_pytorch.py).
+ *
+ * Conventions
+ *  - Activations are channels-last bf16: a tensor (B, C, F, H, W) of the reference is held as
+ *    rows [B*F*H*W][C], row index ((b*F + f)*H + y)*W + x.
+ *  - All pointers are device pointers unless a function is marked HOST.
+ *  - Every function enqueues on `stream` and returns immediately; nothing allocates, frees or
+ *    synchronises, no pointer is retained after the call (graph-capture safe).
+ *  - Return value: 0 on success, a negative vdmi_status otherwise; vdmi_strerror() names it.
+ *    No C++ exception crosses this boundary.
+ */
+#ifndef VDMI_H
+#define VDMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vdmi_stream;            /* hipStream_t */
+
+enum vdmi_status {
+    VDMI_OK = 0,
+    VDMI_E_ARG = -1,                  /* null pointer / bad enum / inconsistent sizes */
+    VDMI_E_SHAPE = -2,                /* shape outside what the kernels support       */
+    VDMI_E_ALIGN = -3,                /* pointer or leading dimension not 16-byte aligned */
+    VDMI_E_LAUNCH = -4,               /* hipLaunchKernel reported an error            */
+    VDMI_E_LDS = -5                   /* tile does not fit the 160 KiB LDS            */
+};
+
+const char* vdmi_strerror(int status);            /* HOST */
+int vdmi_version(void);                           /* HOST */
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM "tap" convolution with fused epilogues.
+ *
+ *   out[pix][n] = EPILOGUE( sum_{tap, cin} W[n][cin][tap] * in[pix*stride + (dy,dx)_tap][cin] )
+ *
+ * One kernel family covers, through the tap table and the epilogue:
+ *   Block.proj (1,3,3) conv + RMSNorm + (scale+1)/shift + SiLU        vdp.py:412-427, 391-398
+ *   ResnetBlock residual (1x1 res_conv or identity), fused            vdp.py:439, 452
+ *   Downsample (1,4,4)/s2 conv, Upsample transposed conv (4 phases)   vdp.py:374-378
+ *   PreNorm LayerNorm folded into to_qkv (Linear / Conv2d 1x1)        vdp.py:380-389, 400-408, 460, 560
+ *   q scaling + rotary on q,k                                         vdp.py:579-583
+ *   SpatialLinearAttention q softmax / k,v transposed staging         vdp.py:467-473
+ *   to_out projections + residual add                                 vdp.py:331-337, 478, 612
+ *   torch.cat skip connections: two input tensors read in place       vdp.py:817, 830
+ * ------------------------------------------------------------------------------------------ */
+
+#define VDMI_MAX_TAPS 16
+
+enum vdmi_epilogue {
+    VDMI_EPI_PLAIN = 0,      /* + bias, + optional identity residual                       */
+    VDMI_EPI_NORM_SILU = 1,  /* + bias, RMSNorm over n, *gain[b] + shift[b], SiLU, + residual */
+    VDMI_EPI_QKV_ATTN = 2,   /* folded LayerNorm, q*scale, optional rotary on q,k          */
+    VDMI_EPI_QKV_SLA = 3     /* folded LayerNorm, q softmax over head dim * scale -> out;
+                                k,v transposed per frame -> out2                            */
+};
+
+typedef struct vdmi_tap_pass {
+    const void* src0;        /* bf16 [frames*in_h*in_w][c0]                                */
+    const void* src1;        /* optional second tensor, channels appended after src0       */
+    int32_t c0, c1;          /* channels of each source (multiples of 8; c1 = 0 if unused) */
+    int32_t in_h, in_w;      /* input image per frame                                      */
+    int32_t stride;          /* input pixel = grid pixel * stride + (dy, dx)               */
+    int32_t ntaps;
+    int8_t dy[VDMI_MAX_TAPS];
+    int8_t dx[VDMI_MAX_TAPS];
+    const void* w;           /* weights packed by vdmi_pack_taps (bf16)                    */
+    int64_t w_group_stride;  /* elements between per-group weight sets (0: one shared set) */
+    int32_t w_group_frames;  /* frames per weight group (used when w_group_stride != 0)    */
+    int32_t reserved;
+} vdmi_tap_pass;
+
+typedef struct vdmi_tapgemm_args {
+    vdmi_tap_pass main;
+    vdmi_tap_pass res;             /* NORM_SILU only: 1-tap pass added after the activation  */
+    int32_t has_res;               /* 0: none, 1: `res` pass (+res_bias), 2: identity tensor */
+    const void* res_identity;      /* bf16 [out rows][ldo_res], read at column n0            */
+    int32_t ld_res;
+    const float* res_bias;         /* [n] or NULL                                            */
+
+    int32_t frames;                /* B*F                                                    */
+    int32_t frames_per_batch;      /* F: batch index of a frame = frame / F                  */
+    int32_t grid_h, grid_w;        /* tile grid extent per frame (output positions computed) */
+    int32_t out_mul, out_off_y, out_off_x;  /* output pixel = grid pixel*out_mul + off       */
+    int32_t out_h, out_w;          /* output image per frame                                 */
+    void* out;                     /* bf16 [frames*out_h*out_w][ldo]                         */
+    int32_t ldo;
+    int32_t n;                     /* output channels (multiple of 32)                       */
+    int32_t epilogue;              /* enum vdmi_epilogue                                     */
+
+    const float* bias;             /* [n] or NULL                                            */
+    const float* gain;             /* NORM: gamma*(scale+1), [B][gain_bstride]               */
+    const float* shift;            /* NORM: shift, [B][shift_bstride] or NULL                */
+    int64_t gain_bstride, shift_bstride;   /* 0: same vector for every batch element        */
+    float norm_scale;              /* sqrt(n)                                                */
+
+    const float* colsum;           /* QKV: sum_k W'[n][k] of the packed (bf16) weights       */
+    float ln_eps;
+    float q_scale;
+    const float* rot_cos;          /* [rot_frames][16] or NULL (no rotary)                   */
+    const float* rot_sin;
+    int32_t rot_frames;            /* F                                                      */
+    int32_t rot_hw;                /* H*W: position of a row = (row / rot_hw) % rot_frames   */
+    void* out2;                    /* QKV_SLA: bf16 [frames][512][sla_hw] (k then v)         */
+    int32_t sla_hw;
+    int32_t reserved;
+} vdmi_tapgemm_args;
+
+/* HOST. Tile the library will use for (epilogue, n): *bn = output-channel tile, *bkc = input
+ * channel chunk.  Weights must be packed with the same bkc and n padded to a multiple of bn. */
+int vdmi_tapgemm_tile(int epilogue, int n, int* bn, int* bkc);
+
+/* HOST. Pack float weights w[n][cin0+cin1][ntaps] into the fragment order the kernel streams:
+ * [chunk][tap][npad/32][bkc/16][64 lanes][8] bf16, each source's channels padded to a multiple
+ * of bkc.  `out` holds vdmi_pack_taps_elems() uint16 values.  If colsum != NULL it receives
+ * sum over (cin, tap) of the bf16-rounded weights per output channel (float[n]). */
+size_t vdmi_pack_taps_elems(int n, int npad, int cin0, int cin1, int ntaps, int bkc);
+int vdmi_pack_taps(const float* w, int n, int npad, int cin0, int cin1, int ntaps, int bkc,
+                   uint16_t* out, float* colsum);
+
+int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Softmax attention core over a small token axis (temporal attention over frames with
+ * relative-position bias, vdp.py:585-612; mid spatial attention, vdp.py:708-710).
+ * qkv: bf16 [rows][3*heads*32] (q already scaled and rotated), out: bf16 [rows][heads*32].
+ * Row m = outer*(n_tok*tok_stride) + i*tok_stride + inner; tokens of one group share
+ * (outer, inner).  bias: float [heads][n_tok][n_tok] or NULL.  dim_head is 32.
+ * ------------------------------------------------------------------------------------------ */
+int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int heads, int n_tok, int64_t tok_stride,
+                   const float* bias, vdmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SpatialLinearAttention pass 1 (vdp.py:471-476): per (frame, head) softmax of k over the
+ * n = H*W positions, context = k·vᵀ (32x32), folded into the output projection:
+ *   W'[frame][c][h*32+d] = sum_e to_out.weight[c][h*32+e] * context[h][d][e]
+ * written in vdmi_pack_taps order (1 tap, cin = heads*32) so that pass 2 is vdmi_tapgemm with
+ * per-frame weights over the softmaxed q.
+ * kvT: bf16 [frames][2*heads*32][hw] from VDMI_EPI_QKV_SLA; w_out: float [c][heads*32].
+ * ------------------------------------------------------------------------------------------ */
+int vdmi_sla_context(const void* kvT, int frames, int heads, int hw, const float* w_out, int c, int cpad,
+                     int bkc, void* w_folded, vdmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Unet3D.init_conv (vdp.py:644,772): Conv3d(cin -> cout, (1,k,k), pad k/2) on the float32
+ * channels-first input x (B, cin, F, H, W); writes channels-last bf16 [B*F*H*W][cout].
+ * w: float [cout][cin][k][k], bias: float [cout].
+ * ------------------------------------------------------------------------------------------ */
+int vdmi_init_conv(const float* x, const float* w, const float* bias, void* out,
+                   int b, int cin, int f, int h, int wd, int cout, int ksize, vdmi_stream stream);
+
+/* final_conv[1] (vdp.py:728): 1x1 conv bf16 [rows][cin] -> float32 channels-first (B, cout, F, H, W). */
+int vdmi_final_conv(const void* in, const float* w, const float* bias, float* out,
+                    int b, int cin, int f, int h, int wd, int cout, vdmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Time / condition embedding (vdp.py:339-351, 651-656, 778-781) and every ResnetBlock.mlp
+ * (vdp.py:432-435, 446-448) in two launches.
+ *   emb[b] = [ Linear(GELU(Linear(sinusoidal(t[b])))) , cond'[b] ]   (cond' = null_cond_emb where null_mask[b])
+ *   for every block k: (scale, shift) = Linear_k(SiLU(emb[b]));  gain = gamma_k*(scale+1)
+ * w_all: float [rows_total][emb_dim] = the blocks' mlp.1.weight stacked (scale rows then shift
+ * rows per block), b_all likewise, gamma_all: float [rows_total/2] stacked RMSNorm gammas.
+ * gain/shift out: float [B][rows_total/2].
+ * ------------------------------------------------------------------------------------------ */
+int vdmi_time_embed(const int64_t* t, int b, int dim, const float* w1, const float* b1, const float* w2,
+                    const float* b2, const float* cond, const float* null_cond, const uint8_t* null_mask,
+                    int cond_dim, float* emb_silu, float* emb_raw, vdmi_stream stream);
+int vdmi_block_scale_shift(const float* emb_silu, int b, int emb_dim, const float* w_all, const float* b_all,
+                           const float* gamma_all, const int32_t* block_offsets, const int32_t* block_channels,
+                           int nblocks, int half_total, float* gain, float* shift, vdmi_stream stream);
+
+/* HOST. RelativePositionBias bucket ids (vdp.py:286-304), int32 [n][n], entry (i,j) = query i, key j. */
+int vdmi_relpos_buckets(int n, int num_buckets, int max_distance, int32_t* out);
+
+/* ------------------------------------------------------------------------------------------
+ * One DDPM ancestral step (vdp.py:939-952, 985-1002; coefficient gather = extract, vdp.py:835-838):
+ *   x0 = srac[t]*x - srmac[t]*eps;  x0 = clamp(x0,-1,1) if clip
+ *   x' = c1[t]*x0 + c2[t]*x + (t != 0) * exp(0.5*logvar[t]) * z
+ * x, eps, out: float32 [b][per_sample]; t: int64 [b] on the device.  z: float32 noise, or NULL to
+ * draw it in-kernel (Philox4x32-10 + Box-Muller, keyed by seed and the element counter+offset).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vdmi_ddpm_coefs {
+    const float* sqrt_recip_alphas_cumprod;
+    const float* sqrt_recipm1_alphas_cumprod;
+    const float* posterior_mean_coef1;
+    const float* posterior_mean_coef2;
+    const float* posterior_log_variance_clipped;
+} vdmi_ddpm_coefs;
+
+int vdmi_ddpm_step(const float* x, const float* eps, const float* z, const int64_t* t,
+                   const vdmi_ddpm_coefs* coefs, float* out, int b, int64_t per_sample, int clip,
+                   uint64_t seed, uint64_t offset, vdmi_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDMI_H */

@@ -1,0 +1,129 @@
+"""CPU: the oracle restatement against fixtures produced by the REAL reference (tests/golden)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vdm_oracle as O
+from tests.helpers import (CFG0, CFG1, CFG3, TINY, TINY_COND, golden, inp, make_unet, oracle_cfg, rel_err)
+
+TOL = 2e-5   # fp32 vs fp32, different op order only
+
+
+@pytest.mark.parametrize("T", [8, 250, 1000])
+def test_schedule_buffers(T):
+    g = golden(f"schedule_T{T}")
+    bufs = O.diffusion_buffers(T)
+    assert set(bufs) == set(g)
+    for k in bufs:
+        assert bufs[k].dtype == torch.float32
+        assert torch.equal(bufs[k], g[k]), k          # same float64 recipe -> bit identical
+
+
+def test_relpos_buckets():
+    g = golden("relpos_buckets")
+    for k, v in g.items():
+        _, md, n = k.split("_")
+        got = O.relpos_bucket(int(n[1:]), 32, int(md[2:]))
+        assert torch.equal(got, v), k
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    m = make_unet(**TINY)
+    return m.state_dict(), oracle_cfg(**TINY), golden("tiny_ops")
+
+
+def test_tiny_submodules(tiny):
+    sd, cfg, g = tiny
+    B, _, Fr, H, _ = [int(v) for v in g["shape"]]
+    t = g["t"]
+    a32 = inp("tiny.a32", (B, 32, Fr, H, H))
+    a32h = inp("tiny.a32h", (B, 32, Fr, H // 2, H // 2))
+    a64h = inp("tiny.a64h", (B, 64, Fr, H // 2, H // 2), scale=1.5)
+    a128h = inp("tiny.a128h", (B, 128, Fr, H // 2, H // 2))
+    a64 = inp("tiny.a64", (B, 64, Fr, H, H))
+    x_in = inp("tiny.x", (B, 3, Fr, H, H))
+    bias = O.relpos_bias(sd["time_rel_pos_bias.relative_attention_bias.weight"], Fr, 32, 32)
+    temb = O.time_mlp(sd, t, cfg.dim)
+    got = {
+        "relpos_bias": bias,
+        "time_mlp": temb,
+        "init_conv": O.conv_1kk(x_in, sd["init_conv.weight"], sd["init_conv.bias"], pad=3),
+        "init_temporal_attn": O.temporal_attn_residual(sd, "init_temporal_attn", a32, cfg, bias),
+        "downs_0_0": O.resnet_block(sd, "downs.0.0", a32, temb),
+        "downs_1_0": O.resnet_block(sd, "downs.1.0", a32h, temb),
+        "downs_1_1": O.resnet_block(sd, "downs.1.1", a64h, temb),
+        "downs_0_2": O.sla_residual(sd, "downs.0.2", a32, cfg),
+        "downs_1_2": O.sla_residual(sd, "downs.1.2", a64h, cfg),
+        "downs_0_3": O.temporal_attn_residual(sd, "downs.0.3", a32, cfg, bias),
+        "downs_0_4": O.downsample(sd, "downs.0.4", a32),
+        "ups_0_4": O.upsample(sd, "ups.0.4", a32h),
+        "ups_0_0": O.resnet_block(sd, "ups.0.0", a128h, temb),
+        "mid_block1": O.resnet_block(sd, "mid_block1", a64h, temb),
+        "mid_spatial_attn": O.spatial_attn_residual(sd, "mid_spatial_attn", a64h, cfg),
+        "mid_temporal_attn": O.temporal_attn_residual(sd, "mid_temporal_attn", a64h, cfg, bias),
+        "final_conv_0": O.resnet_block(sd, "final_conv.0", a64, None),
+        "final_conv_1": O.conv_1kk(a32, sd["final_conv.1.weight"], sd["final_conv.1.bias"], pad=0),
+        "block1_noss": O.block(sd, "downs.0.0.block1", a32),
+        "eps": O.unet3d_forward(sd, cfg, x_in, t),
+    }
+    for k, v in got.items():
+        assert v.shape == g[k].shape, k
+        assert rel_err(v, g[k]) < TOL, (k, rel_err(v, g[k]))
+
+
+def test_tiny_cond():
+    m = make_unet(salt=1, **TINY_COND)
+    sd, cfg, g = m.state_dict(), oracle_cfg(**TINY_COND), golden("tiny_cond")
+    x_in = inp("tiny.x", (2, 3, 4, 12, 12))
+    assert rel_err(O.unet3d_forward(sd, cfg, x_in, g["t"], g["cond"], False), g["eps_cond"]) < TOL
+    assert rel_err(O.unet3d_forward(sd, cfg, x_in, g["t"], g["cond"], True), g["eps_null"]) < TOL
+    assert rel_err(O.unet3d_forward_cfg(sd, cfg, x_in, g["t"], g["cond"], 2.0), g["eps_cfg2"]) < TOL
+
+
+def test_p_sample_step():
+    g = golden("p_sample_step_T250")
+    shape = (4, 3, 4, 12, 12)
+    x, e, z = inp("step.x", shape, scale=1.2), inp("step.eps", shape), inp("step.z", shape)
+    out = O.p_sample_step(O.diffusion_buffers(250), x, g["t"], e, z)
+    assert rel_err(out, g["out"]) < 1e-6
+    # t == 0 adds no noise
+    assert torch.equal(out[0], O.p_sample_step(O.diffusion_buffers(250), x, g["t"], e, z * 0)[0])
+
+
+def test_tiny_loop(tiny):
+    sd, cfg, _ = tiny
+    g = golden("tiny_loop_T8")
+    shape = (2, 3, 4, 12, 12)
+    x_T = inp("tiny.xT", shape)
+    noises = [inp(f"tiny.z{k}", shape) for k in range(8)]
+    out = O.p_sample_loop(sd, cfg, O.diffusion_buffers(8), x_T, noises)
+    assert rel_err(out, g["final"]) < 1e-4
+
+
+def test_cfg0_eps_and_traj():
+    m = make_unet(**CFG0)
+    sd, cfg, g = m.state_dict(), oracle_cfg(**CFG0), golden("cfg0_eps")
+    x = inp("cfg0.x", (1, 3, 5, 32, 32))
+    for tt in (0, 125, 249):
+        assert rel_err(O.unet3d_forward(sd, cfg, x, torch.tensor([tt])), g[f"eps_t{tt}"]) < TOL, tt
+    gt = golden("cfg0_traj6")
+    shape = (1, 3, 5, 32, 32)
+    out = O.p_sample_loop(sd, cfg, O.diffusion_buffers(250), inp("cfg0.xT", shape),
+                          [inp(f"cfg0.z{k}", shape) for k in range(6)], steps=6)
+    assert rel_err(out, gt["out"]) < 1e-4
+
+
+def test_cfg1_eps():
+    m = make_unet(**CFG1)
+    g = golden("cfg1_eps")
+    x = inp("cfg1.x", (2, 1, 10, 64, 64))
+    assert rel_err(O.unet3d_forward(m.state_dict(), oracle_cfg(**CFG1), x, g["t"]), g["eps"]) < TOL
+
+
+def test_cfg3_eps_cfg():
+    m = make_unet(**CFG3)
+    g = golden("cfg3_eps")
+    x, c = inp("cfg3.x", (1, 3, 16, 64, 64)), inp("cfg3.cond", (1, 768))
+    out = O.unet3d_forward_cfg(m.state_dict(), oracle_cfg(**CFG3), x, g["t"], c, 2.0)
+    assert rel_err(out, g["eps_cfg2"]) < TOL

@@ -1,0 +1,117 @@
+"""ctypes binding of libvdmi.so (declarations mirror include/vdmi.h).
+
+There is no fallback: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvdmi.so")
+
+MAX_TAPS = 16
+EPI_PLAIN, EPI_NORM_SILU, EPI_QKV_ATTN, EPI_QKV_SLA = 0, 1, 2, 3
+
+
+class TapPass(C.Structure):
+    _fields_ = [
+        ("src0", C.c_void_p), ("src1", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32),
+        ("in_h", C.c_int32), ("in_w", C.c_int32),
+        ("stride", C.c_int32), ("ntaps", C.c_int32),
+        ("dy", C.c_int8 * MAX_TAPS), ("dx", C.c_int8 * MAX_TAPS),
+        ("w", C.c_void_p),
+        ("w_group_stride", C.c_int64),
+        ("w_group_frames", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class TapGemmArgs(C.Structure):
+    _fields_ = [
+        ("main", TapPass), ("res", TapPass),
+        ("has_res", C.c_int32),
+        ("res_identity", C.c_void_p),
+        ("ld_res", C.c_int32),
+        ("res_bias", C.c_void_p),
+        ("frames", C.c_int32), ("frames_per_batch", C.c_int32),
+        ("grid_h", C.c_int32), ("grid_w", C.c_int32),
+        ("out_mul", C.c_int32), ("out_off_y", C.c_int32), ("out_off_x", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int32), ("n", C.c_int32), ("epilogue", C.c_int32),
+        ("bias", C.c_void_p), ("gain", C.c_void_p), ("shift", C.c_void_p),
+        ("gain_bstride", C.c_int64), ("shift_bstride", C.c_int64),
+        ("norm_scale", C.c_float),
+        ("colsum", C.c_void_p),
+        ("ln_eps", C.c_float), ("q_scale", C.c_float),
+        ("rot_cos", C.c_void_p), ("rot_sin", C.c_void_p),
+        ("rot_frames", C.c_int32), ("rot_hw", C.c_int32),
+        ("out2", C.c_void_p),
+        ("sla_hw", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class DdpmCoefs(C.Structure):
+    _fields_ = [
+        ("sqrt_recip_alphas_cumprod", C.c_void_p),
+        ("sqrt_recipm1_alphas_cumprod", C.c_void_p),
+        ("posterior_mean_coef1", C.c_void_p),
+        ("posterior_mean_coef2", C.c_void_p),
+        ("posterior_log_variance_clipped", C.c_void_p),
+    ]
+
+
+class VdmiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGNATURES = {
+    "vdmi_strerror": (C.c_char_p, [C.c_int]),
+    "vdmi_version": (C.c_int, []),
+    "vdmi_tapgemm_tile": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vdmi_pack_taps_elems": (C.c_size_t, [C.c_int] * 6),
+    "vdmi_pack_taps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p]),
+    "vdmi_tapgemm": (C.c_int, [C.POINTER(TapGemmArgs), C.c_void_p]),
+    "vdmi_attn_core": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64,
+                                 C.c_void_p, C.c_void_p]),
+    "vdmi_sla_context": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_void_p]),
+    "vdmi_init_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
+    "vdmi_final_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "vdmi_time_embed": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] +
+                        [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdmi_block_scale_shift": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 +
+                               [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdmi_relpos_buckets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vdmi_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs),
+                                 C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """The loaded library; raises if libvdmi.so has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VdmiError(
+                f"{LIB_PATH} is missing: build it with `make -C video_diffusion_amd/csrc` "
+                "(or __graft_entry__.build()). There is no non-HIP fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(status: int, what: str = "vdmi call"):
+    if status != 0:
+        msg = lib().vdmi_strerror(status).decode()
+        raise VdmiError(f"{what} failed: {msg} (status {status})")

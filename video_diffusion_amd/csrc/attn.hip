@@ -1,0 +1,207 @@
+// Attention cores for gfx950.
+//  * vdmi_attn_core   — softmax attention over a small token axis (frames, or the 8x8 bottleneck
+//                       positions); one lane per (row, head), online softmax in fp32.
+//  * vdmi_sla_context — SpatialLinearAttention pass 1: softmax of k over positions, 32x32 context
+//                       per (frame, head) on the matrix cores, folded into to_out's weights.
+#include "vdmi_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void attn_core_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+                                                        long long rows, int heads, int n_tok, long long tok_stride,
+                                                        const float* __restrict__ bias) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long m = gid / heads;
+    const int hd = (int)(gid - m * heads);
+    if (m >= rows) return;
+    const int hid = heads * 32, ld = 3 * hid;
+    const long long span = (long long)n_tok * tok_stride;
+    const long long outer = m / span, rem = m - outer * span;
+    const int i = (int)(rem / tok_stride);
+    const long long base = outer * span + (rem - (long long)i * tok_stride);
+
+    float q[32], o[32];
+    {
+        const bf16x8* qp = reinterpret_cast<const bf16x8*>(qkv + m * ld + hd * 32);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bf16x8 t = qp[v];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[v * 8 + e] = (float)t[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) o[e] = 0.f;
+    float mx = -INFINITY, l = 0.f;
+    const float* brow = bias ? bias + ((long long)hd * n_tok + i) * n_tok : nullptr;
+    for (int j = 0; j < n_tok; ++j) {
+        const long long mj = base + (long long)j * tok_stride;
+        const bf16x8* kp = reinterpret_cast<const bf16x8*>(qkv + mj * ld + hid + hd * 32);
+        const bf16x8* vp = reinterpret_cast<const bf16x8*>(qkv + mj * ld + 2 * hid + hd * 32);
+        float s = brow ? brow[j] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bf16x8 t = kp[v];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += q[v * 8 + e] * (float)t[e];
+        }
+        const float mn = fmaxf(mx, s);
+        const float corr = __expf(mx - mn), p = __expf(s - mn);
+        l = l * corr + p;
+        mx = mn;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bf16x8 t = vp[v];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[v * 8 + e] = o[v * 8 + e] * corr + p * (float)t[e];
+        }
+    }
+    const float inv = 1.0f / l;
+    bf16x8* op = reinterpret_cast<bf16x8*>(out + m * hid + hd * 32);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = f2bf(o[v * 8 + e] * inv);
+        op[v] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SLA context.  One workgroup per (frame, head); 4 waves split the positions.
+// ------------------------------------------------------------------------------------------
+constexpr int SLA_CH = 256;            // positions per chunk
+constexpr int SLA_ROW = SLA_CH + 8;    // padded LDS row (elements)
+
+__global__ __launch_bounds__(256) void sla_context_kernel(const __bf16* __restrict__ kvT, int heads, int hw,
+                                                          const float* __restrict__ w_out, int c, int cpad, int bkc,
+                                                          __bf16* __restrict__ w_folded) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ek[32 * SLA_ROW];
+    __shared__ __attribute__((aligned(16))) __bf16 Vv[32 * SLA_ROW];
+    __shared__ float ctx[4][32][33];
+    __shared__ float rowmax[32], rowsum[32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frame = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int hid = heads * 32;
+    const int r = tid >> 3, part = tid & 7;        // loader: row r, 8 threads per row
+    const __bf16* krow = kvT + ((long long)frame * 2 * hid + hd * 32 + r) * hw;
+    const __bf16* vrow = kvT + ((long long)frame * 2 * hid + hid + hd * 32 + r) * hw;
+    const bool vec = (hw % 8) == 0;
+
+    // pass A: max over positions of each k row
+    float mx = -INFINITY;
+    if (vec) {
+        for (int n = part * 8; n < hw; n += 64) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(krow + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)t[e]);
+        }
+    } else {
+        for (int n = part; n < hw; n += 8) mx = fmaxf(mx, (float)krow[n]);
+    }
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float lsum = 0.f;
+
+    for (int n0 = 0; n0 < hw; n0 += SLA_CH) {
+        __syncthreads();
+        // each loader thread fills 32 consecutive positions of its row in both tiles
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int nl = part * 32 + v * 8, n = n0 + nl;
+            bf16x8 kk, vv;
+            if (vec && n + 8 <= hw) {
+                kk = *reinterpret_cast<const bf16x8*>(krow + n);
+                vv = *reinterpret_cast<const bf16x8*>(vrow + n);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = n + e < hw;
+                    kk[e] = ok ? krow[n + e] : (__bf16)(-INFINITY);
+                    vv[e] = ok ? vrow[n + e] : (__bf16)0.f;
+                }
+            }
+            bf16x8 ee;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 x = f2bf(__expf((float)kk[e] - mx));
+                ee[e] = x;
+                lsum += (float)x;
+            }
+            *reinterpret_cast<bf16x8*>(Ek + r * SLA_ROW + nl) = ee;
+            *reinterpret_cast<bf16x8*>(Vv + r * SLA_ROW + nl) = vv;
+        }
+        __syncthreads();
+        // ctx[d][e] += sum_n E[d][n] * V[e][n]; this wave takes positions [wave*64, wave*64+64)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int off = (lane & 31) * SLA_ROW + wave * 64 + kk * 16 + 8 * (lane >> 5);
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ek + off);
+            const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(Vv + off);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) lsum += __shfl_xor(lsum, s);
+    if (part == 0) { rowsum[r] = lsum; rowmax[r] = mx; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ctx[wave][(i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)][lane & 31] = acc[i];
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        const int d = idx >> 5, e = idx & 31;
+        ctx[0][d][e] = (ctx[0][d][e] + ctx[1][d][e] + ctx[2][d][e] + ctx[3][d][e]) / rowsum[d];
+    }
+    __syncthreads();
+
+    // fold into the output projection and write in vdmi_pack_taps order (1 tap, cin = heads*32)
+    __bf16* wf = w_folded + (long long)frame * hid * cpad;
+    const int ksper = bkc / 16, ctn = cpad / 32;
+    for (int idx = tid; idx < c * 32; idx += 256) {
+        const int co = idx >> 5, d = idx & 31;
+        const float* wr = w_out + (long long)co * hid + hd * 32;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) s += wr[e] * ctx[0][d][e];
+        const int k = hd * 32 + d;
+        const int chunk = k / bkc, kin = k % bkc, ks = kin >> 4, half = (kin >> 3) & 1, j = kin & 7;
+        const int ct = co >> 5, ln = half * 32 + (co & 31);
+        wf[((((long long)chunk * ctn + ct) * ksper + ks) * 64 + ln) * 8 + j] = f2bf(s);
+    }
+}
+
+}   // namespace
+
+extern "C" int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int heads, int n_tok, int64_t tok_stride,
+                              const float* bias, vdmi_stream stream) {
+    if (!qkv || !out) return VDMI_E_ARG;
+    if (rows <= 0 || heads <= 0 || n_tok <= 0 || tok_stride <= 0 || rows % ((int64_t)n_tok * tok_stride))
+        return VDMI_E_SHAPE;
+    if (!aligned16(qkv) || !aligned16(out)) return VDMI_E_ALIGN;
+    const long long threads = (long long)rows * heads;
+    const long long blocks = (threads + 255) / 256;
+    if (blocks > 0x7fffffffLL) return VDMI_E_SHAPE;
+    hipLaunchKernelGGL(attn_core_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), (long long)rows, heads, n_tok,
+                       (long long)tok_stride, bias);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_sla_context(const void* kvT, int frames, int heads, int hw, const float* w_out, int c, int cpad,
+                                int bkc, void* w_folded, vdmi_stream stream) {
+    if (!kvT || !w_out || !w_folded) return VDMI_E_ARG;
+    if (frames <= 0 || heads <= 0 || hw <= 0 || c <= 0 || cpad < c || cpad % 32 || (bkc != 32 && bkc != 64) ||
+        (heads * 32) % bkc)
+        return VDMI_E_SHAPE;
+    if (!aligned16(kvT) || !aligned16(w_folded)) return VDMI_E_ALIGN;
+    hipLaunchKernelGGL(sla_context_kernel, dim3((unsigned)(frames * heads)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const __bf16*>(kvT), heads, hw, w_out, c, cpad,
+                       bkc, static_cast<__bf16*>(w_folded));
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}

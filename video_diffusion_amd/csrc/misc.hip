@@ -1,0 +1,371 @@
+// Small kernels of the denoising path for gfx950: init conv, final 1x1 conv, time/condition
+// embedding, per-block scale/shift tables and the fused DDPM posterior step.
+#include "vdmi_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// init conv: float32 channels-first input -> bf16 channels-last, direct convolution.
+// One workgroup per 16x16 pixel tile of one frame; weights [cin*k*k][cout] and the haloed input
+// patch live in LDS; one lane per pixel, 16 output channels at a time.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, __bf16* __restrict__ out,
+                                                        int cin, int nf, int h, int wd, int cout, int ks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pdim = 16 + ks - 1, pad = ks / 2, kk = ks * ks;
+    float* wl = reinterpret_cast<float*>(smem);                 // [cin*kk][cout]
+    float* pl = wl + (size_t)cin * kk * cout;                   // [cin][pdim][pdim]
+    const int tid = threadIdx.x;
+    const int tiles_x = (wd + 15) / 16;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int frame = blockIdx.y;                               // b*nf + f
+    const int b = frame / nf, f = frame % nf;
+
+    for (int idx = tid; idx < cin * kk * cout; idx += 256) {
+        const int co = idx % cout, rest = idx / cout;           // rest = ci*kk + tap
+        wl[idx] = w[(size_t)co * cin * kk + rest];
+    }
+    const int y0 = ty * 16 - pad, x0 = tx * 16 - pad;
+    for (int idx = tid; idx < cin * pdim * pdim; idx += 256) {
+        const int ci = idx / (pdim * pdim), rem = idx % (pdim * pdim);
+        const int iy = y0 + rem / pdim, ix = x0 + rem % pdim;
+        float v = 0.f;
+        if (iy >= 0 && iy < h && ix >= 0 && ix < wd)
+            v = x[(((size_t)b * cin + ci) * nf + f) * h * wd + (size_t)iy * wd + ix];
+        pl[idx] = v;
+    }
+    __syncthreads();
+
+    const int py = tid >> 4, px = tid & 15;
+    const int oy = ty * 16 + py, ox = tx * 16 + px;
+    const bool valid = oy < h && ox < wd;
+    const size_t orow = ((size_t)frame * h + oy) * wd + ox;
+    for (int c0 = 0; c0 < cout; c0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = bias ? bias[c0 + e] : 0.f;
+        for (int ci = 0; ci < cin; ++ci)
+            for (int ky = 0; ky < ks; ++ky)
+                for (int kx = 0; kx < ks; ++kx) {
+                    const float v = pl[(ci * pdim + py + ky) * pdim + px + kx];
+                    const float* wr = wl + (size_t)((ci * ks + ky) * ks + kx) * cout + c0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * q + e] += v * w4[e];
+                    }
+                }
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[8 * q + e]);
+                *reinterpret_cast<bf16x8*>(out + orow * cout + c0 + 8 * q) = o;
+            }
+        }
+    }
+}
+
+// final 1x1 conv: bf16 rows -> float32 channels-first.  One lane per pixel.
+__global__ __launch_bounds__(256) void final_conv_kernel(const __bf16* __restrict__ in, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         long long rows, int cin, int nf, long long hw, int cout) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = (o < cout && bias) ? bias[o] : 0.f;
+    const bf16x8* ip = reinterpret_cast<const bf16x8*>(in + m * cin);
+    for (int c8 = 0; c8 < cin / 8; ++c8) {
+        const bf16x8 t = ip[c8];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < cout) {
+                const float* wr = w + (size_t)o * cin + c8 * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[o] += v[e] * wr[e];
+            }
+    }
+    const long long frame = m / hw, s = m - frame * hw;
+    const long long b = frame / nf, f = frame - b * nf;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+        if (o < cout) out[((b * cout + o) * nf + f) * hw + s] = acc[o];
+}
+
+// ------------------------------------------------------------------------------------------
+// time embedding: one workgroup per batch element.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restrict__ t, int dim,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         const float* __restrict__ cond, const float* __restrict__ null_cond,
+                                                         const uint8_t* __restrict__ null_mask, int cond_dim,
+                                                         float* __restrict__ emb_silu, float* __restrict__ emb_raw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* e0 = reinterpret_cast<float*>(smem);   // [dim]
+    float* h1 = e0 + dim;                         // [8*dim]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int td = 8 * dim, half = dim / 2, ed = td + cond_dim;
+    const float tv = (float)t[b];
+    const float step = logf(10000.0f) / (float)(half - 1);
+    for (int k = tid; k < half; k += 256) {
+        const float ang = tv * expf((float)k * -step);
+        e0[k] = sinf(ang);
+        e0[half + k] = cosf(ang);
+    }
+    __syncthreads();
+    for (int j = wave; j < td; j += 4) {
+        float s = 0.f;
+        for (int k = lane; k < dim; k += 64) s += w1[(size_t)j * dim + k] * e0[k];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float v = s + b1[j];
+            h1[j] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact GELU
+        }
+    }
+    __syncthreads();
+    for (int j = wave; j < td; j += 4) {
+        float s = 0.f;
+        for (int k = lane; k < td; k += 64) s += w2[(size_t)j * td + k] * h1[k];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float v = s + b2[j];
+            emb_raw[(size_t)b * ed + j] = v;
+            emb_silu[(size_t)b * ed + j] = silu_f(v);
+        }
+    }
+    for (int k = tid; k < cond_dim; k += 256) {
+        const bool nul = null_mask && null_mask[b];
+        const float v = nul ? null_cond[k] : cond[(size_t)b * cond_dim + k];
+        emb_raw[(size_t)b * ed + td + k] = v;
+        emb_silu[(size_t)b * ed + td + k] = silu_f(v);
+    }
+}
+
+// every ResnetBlock.mlp Linear at once: one wave per (block, channel), both the scale and the shift row
+__global__ __launch_bounds__(256) void block_scale_shift_kernel(const float* __restrict__ emb_silu, int nb, int emb_dim,
+                                                                const float* __restrict__ w_all, const float* __restrict__ b_all,
+                                                                const float* __restrict__ gamma_all,
+                                                                const int32_t* __restrict__ block_offsets,
+                                                                const int32_t* __restrict__ block_channels, int nblocks,
+                                                                int half_total, float* __restrict__ gain,
+                                                                float* __restrict__ shift) {
+    const int lane = threadIdx.x & 63;
+    const int hr = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (hr >= half_total) return;
+    int k = 0;
+    while (k + 1 < nblocks && block_offsets[k + 1] <= hr) ++k;
+    const int off = block_offsets[k], ch = block_channels[k], c = hr - off;
+    const float* wsc = w_all + (size_t)(2 * off + c) * emb_dim;
+    const float* wsh = w_all + (size_t)(2 * off + ch + c) * emb_dim;
+    const float bsc = b_all[2 * off + c], bsh = b_all[2 * off + ch + c];
+    const float g = gamma_all[hr];
+    for (int b = 0; b < nb; ++b) {
+        const float* e = emb_silu + (size_t)b * emb_dim;
+        float s0 = 0.f, s1 = 0.f;
+        for (int q = lane; q < emb_dim; q += 64) {
+            const float ev = e[q];
+            s0 += wsc[q] * ev;
+            s1 += wsh[q] * ev;
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) {
+            gain[(size_t)b * half_total + hr] = g * (s0 + bsc + 1.0f);
+            shift[(size_t)b * half_total + hr] = s1 + bsh;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// DDPM step.  Philox4x32-10 (counter = element group + offset, key = seed) + Box-Muller.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__device__ __forceinline__ void normal4(uint64_t group, uint64_t seed, float (&z)[4]) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)group, (uint32_t)(group >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float k = 2.3283064365386963e-10f;   // 2^-32
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)r[2 * p] + 1.0f) * k;          // (0, 1]
+        const float u2 = (float)r[2 * p + 1] * k;
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[2 * p] = rad * cs;
+        z[2 * p + 1] = rad * sn;
+    }
+}
+
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                        const float* __restrict__ z, const int64_t* __restrict__ t,
+                                                        vdmi_ddpm_coefs cf, float* __restrict__ out, long long per_sample,
+                                                        long long groups_per_sample, int clip, uint64_t seed,
+                                                        uint64_t offset) {
+    const int b = blockIdx.y;
+    const int64_t tb = t[b];
+    const float a = cf.sqrt_recip_alphas_cumprod[tb], bb = cf.sqrt_recipm1_alphas_cumprod[tb];
+    const float c1 = cf.posterior_mean_coef1[tb], c2 = cf.posterior_mean_coef2[tb];
+    const float sigma = tb != 0 ? expf(0.5f * cf.posterior_log_variance_clipped[tb]) : 0.f;
+    const long long base = (long long)b * per_sample;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups_per_sample; g += (long long)gridDim.x * 256) {
+        const long long i0 = g * 4;
+        const int cnt = (int)((per_sample - i0) < 4 ? (per_sample - i0) : 4);
+        float xv[4], ev[4], zv[4];
+        if (cnt == 4 && (per_sample & 3) == 0) {
+            const f32x4 xx = *reinterpret_cast<const f32x4*>(x + base + i0);
+            const f32x4 ee = *reinterpret_cast<const f32x4*>(eps + base + i0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[e] = xx[e]; ev[e] = ee[e]; }
+            if (z) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + base + i0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zv[e] = zz[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = e < cnt;
+                xv[e] = ok ? x[base + i0 + e] : 0.f;
+                ev[e] = ok ? eps[base + i0 + e] : 0.f;
+                zv[e] = (ok && z) ? z[base + i0 + e] : 0.f;
+            }
+        }
+        // the counter includes t, which lives on the device, so a captured graph draws fresh noise each replay
+        if (!z)
+            normal4(((uint64_t)tb * gridDim.y + (uint64_t)b) * (uint64_t)groups_per_sample + (uint64_t)g + offset, seed, zv);
+        float ov[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x0 = a * xv[e] - bb * ev[e];
+            if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            ov[e] = c1 * x0 + c2 * xv[e] + sigma * zv[e];
+        }
+        if (cnt == 4 && (per_sample & 3) == 0) {
+            f32x4 oo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oo[e] = ov[e];
+            *reinterpret_cast<f32x4*>(out + base + i0) = oo;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < cnt) out[base + i0 + e] = ov[e];
+        }
+    }
+}
+
+}   // namespace
+
+extern "C" int vdmi_init_conv(const float* x, const float* w, const float* bias, void* out, int b, int cin, int f,
+                              int h, int wd, int cout, int ksize, vdmi_stream stream) {
+    if (!x || !w || !out) return VDMI_E_ARG;
+    if (b <= 0 || cin <= 0 || f <= 0 || h <= 0 || wd <= 0 || cout <= 0 || cout % 16 || ksize < 1 || !(ksize & 1) ||
+        ksize > 15)
+        return VDMI_E_SHAPE;
+    if (!aligned16(out)) return VDMI_E_ALIGN;
+    const int pdim = 16 + ksize - 1;
+    const size_t lds = ((size_t)cin * ksize * ksize * cout + (size_t)cin * pdim * pdim) * 4;
+    if (lds > 160 * 1024) return VDMI_E_LDS;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(init_conv_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return VDMI_E_LAUNCH;
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)(((h + 15) / 16) * ((wd + 15) / 16)), (unsigned)(b * f));
+    hipLaunchKernelGGL(init_conv_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, w, bias,
+                       static_cast<__bf16*>(out), cin, f, h, wd, cout, ksize);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_final_conv(const void* in, const float* w, const float* bias, float* out, int b, int cin, int f,
+                               int h, int wd, int cout, vdmi_stream stream) {
+    if (!in || !w || !out) return VDMI_E_ARG;
+    if (b <= 0 || cin <= 0 || cin % 8 || f <= 0 || h <= 0 || wd <= 0 || cout <= 0 || cout > 8) return VDMI_E_SHAPE;
+    if (!aligned16(in)) return VDMI_E_ALIGN;
+    const long long rows = (long long)b * f * h * wd;
+    hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const __bf16*>(in), w, bias, out, rows, cin, f,
+                       (long long)h * wd, cout);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_time_embed(const int64_t* t, int b, int dim, const float* w1, const float* b1, const float* w2,
+                               const float* b2, const float* cond, const float* null_cond, const uint8_t* null_mask,
+                               int cond_dim, float* emb_silu, float* emb_raw, vdmi_stream stream) {
+    if (!t || !w1 || !b1 || !w2 || !b2 || !emb_silu || !emb_raw) return VDMI_E_ARG;
+    if (b <= 0 || dim < 4 || dim % 2 || cond_dim < 0) return VDMI_E_SHAPE;
+    if (cond_dim > 0 && (!cond || (null_mask && !null_cond))) return VDMI_E_ARG;
+    const size_t lds = (size_t)9 * dim * 4;
+    if (lds > 64 * 1024) return VDMI_E_LDS;
+    hipLaunchKernelGGL(time_embed_kernel, dim3((unsigned)b), dim3(256), lds, static_cast<hipStream_t>(stream), t, dim,
+                       w1, b1, w2, b2, cond, null_cond, null_mask, cond_dim, emb_silu, emb_raw);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_block_scale_shift(const float* emb_silu, int b, int emb_dim, const float* w_all,
+                                      const float* b_all, const float* gamma_all, const int32_t* block_offsets,
+                                      const int32_t* block_channels, int nblocks, int half_total, float* gain,
+                                      float* shift, vdmi_stream stream) {
+    if (!emb_silu || !w_all || !b_all || !gamma_all || !block_offsets || !block_channels || !gain || !shift)
+        return VDMI_E_ARG;
+    if (b <= 0 || emb_dim <= 0 || nblocks <= 0 || half_total <= 0) return VDMI_E_SHAPE;
+    hipLaunchKernelGGL(block_scale_shift_kernel, dim3((unsigned)((half_total + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), emb_silu, b, emb_dim, w_all, b_all, gamma_all, block_offsets,
+                       block_channels, nblocks, half_total, gain, shift);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_ddpm_step(const float* x, const float* eps, const float* z, const int64_t* t,
+                              const vdmi_ddpm_coefs* coefs, float* out, int b, int64_t per_sample, int clip,
+                              uint64_t seed, uint64_t offset, vdmi_stream stream) {
+    if (!x || !eps || !t || !coefs || !out) return VDMI_E_ARG;
+    if (!coefs->sqrt_recip_alphas_cumprod || !coefs->sqrt_recipm1_alphas_cumprod || !coefs->posterior_mean_coef1 ||
+        !coefs->posterior_mean_coef2 || !coefs->posterior_log_variance_clipped)
+        return VDMI_E_ARG;
+    if (b <= 0 || b > 65535 || per_sample <= 0) return VDMI_E_SHAPE;
+    if ((per_sample & 3) == 0 && (!aligned16(x) || !aligned16(eps) || !aligned16(out) || (z && !aligned16(z))))
+        return VDMI_E_ALIGN;
+    const long long groups = (per_sample + 3) / 4;
+    long long bx = (groups + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)bx, (unsigned)b), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, eps, z, t, *coefs, out, (long long)per_sample, groups, clip,
+                       seed, offset);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}

@@ -1,0 +1,26 @@
+// Shared device/host helpers for the vdmi kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vdmi.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define VDMI_WAVE 64
+
+__device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
+__device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }   // v_cvt_pk_bf16_f32, RNE
+
+__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define VDMI_LAUNCH_CHECK()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return VDMI_E_LAUNCH;          \
+    } while (0)

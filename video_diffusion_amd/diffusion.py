@@ -1,0 +1,278 @@
+"""GaussianDiffusion with the reference's surface (vdp.py:835-1182 of the reference =
+video_diffusion_pytorch/video_diffusion_pytorch.py).  The sampling step (predict x0, clip,
+posterior mean, add noise — vdp.py:985-1002) is one HIP kernel (vdmi_ddpm_step); the sequential
+loop replays one captured HIP graph per step when the denoiser is the HIP Unet3D.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from ._lib import DdpmCoefs, check
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+def extract(a, t, x_shape):
+    b, *_ = t.shape
+    out = a.gather(-1, t)
+    return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    # float64 throughout, as the reference (vdp.py:866-872)
+    steps = timesteps + 1
+    x = torch.linspace(0, timesteps, steps, dtype=torch.float64)
+    alphas_cumprod = torch.cos(((x / timesteps) + s) / (1 + s) * torch.pi * 0.5) ** 2
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.9999)
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(
+        self,
+        denoise_fn,
+        vae,
+        image_size,
+        num_frames,
+        channels=3,
+        timesteps=1000,
+        loss_type='l1',
+        use_dynamic_thres=False,
+        dynamic_thres_percentile=0.9,
+        latent_scale=1.0,
+        frame_cond_encoder=None,
+    ):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.num_frames = num_frames
+        self.denoise_fn = denoise_fn
+        self.vae = vae
+        self.frame_cond_encoder = frame_cond_encoder
+        self.latent_scale = latent_scale
+
+        for param in self.vae.parameters():
+            param.requires_grad = False
+
+        betas = cosine_beta_schedule(timesteps)
+        alphas = 1. - betas
+        alphas_cumprod = torch.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.)
+
+        timesteps, = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+
+        register_buffer = lambda name, val: self.register_buffer(name, val.to(torch.float32))
+        register_buffer('betas', betas)
+        register_buffer('alphas_cumprod', alphas_cumprod)
+        register_buffer('alphas_cumprod_prev', alphas_cumprod_prev)
+        register_buffer('sqrt_alphas_cumprod', torch.sqrt(alphas_cumprod))
+        register_buffer('sqrt_one_minus_alphas_cumprod', torch.sqrt(1. - alphas_cumprod))
+        register_buffer('log_one_minus_alphas_cumprod', torch.log(1. - alphas_cumprod))
+        register_buffer('sqrt_recip_alphas_cumprod', torch.sqrt(1. / alphas_cumprod))
+        register_buffer('sqrt_recipm1_alphas_cumprod', torch.sqrt(1. / alphas_cumprod - 1))
+        posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
+        register_buffer('posterior_variance', posterior_variance)
+        register_buffer('posterior_log_variance_clipped', torch.log(posterior_variance.clamp(min=1e-20)))
+        register_buffer('posterior_mean_coef1', betas * torch.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+        register_buffer('posterior_mean_coef2', (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
+
+        self.use_dynamic_thres = use_dynamic_thres
+        self.dynamic_thres_percentile = dynamic_thres_percentile
+
+        # "torch": per-step noise from torch.randn_like (the reference's RNG consumption order);
+        # "philox": drawn inside the step kernel (no extra pass over HBM).
+        self.noise_source = "torch"
+        self.use_hip_graph = True
+        self._graphs = {}
+
+    # -- closed forms kept for API compatibility (elementwise torch expressions) ------------
+    def q_mean_variance(self, x_start, t):
+        mean = extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
+        variance = extract(1. - self.alphas_cumprod, t, x_start.shape)
+        log_variance = extract(self.log_one_minus_alphas_cumprod, t, x_start.shape)
+        return mean, variance, log_variance
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t -
+                extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+    def q_posterior(self, x_start, x_t, t):
+        posterior_mean = (extract(self.posterior_mean_coef1, t, x_t.shape) * x_start +
+                          extract(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        posterior_variance = extract(self.posterior_variance, t, x_t.shape)
+        posterior_log_variance_clipped = extract(self.posterior_log_variance_clipped, t, x_t.shape)
+        return posterior_mean, posterior_variance, posterior_log_variance_clipped
+
+    def _dynamic_clip(self, x_recon):
+        s = torch.quantile(x_recon.reshape(x_recon.shape[0], -1).abs(), self.dynamic_thres_percentile, dim=-1)
+        s.clamp_(min=1.)
+        s = s.view(-1, *((1,) * (x_recon.ndim - 1)))
+        return x_recon.clamp(-s, s) / s
+
+    def p_mean_variance(self, x, t, clip_denoised=True):
+        x_recon = self.predict_start_from_noise(x, t=t, noise=self.denoise_fn(x, t))
+        if clip_denoised:
+            x_recon = self._dynamic_clip(x_recon) if self.use_dynamic_thres else x_recon.clamp(-1., 1.)
+        return self.q_posterior(x_start=x_recon, x_t=x, t=t)
+
+    # -- the fused step ---------------------------------------------------------------------
+    def _coefs(self) -> DdpmCoefs:
+        c = DdpmCoefs()
+        c.sqrt_recip_alphas_cumprod = self.sqrt_recip_alphas_cumprod.data_ptr()
+        c.sqrt_recipm1_alphas_cumprod = self.sqrt_recipm1_alphas_cumprod.data_ptr()
+        c.posterior_mean_coef1 = self.posterior_mean_coef1.data_ptr()
+        c.posterior_mean_coef2 = self.posterior_mean_coef2.data_ptr()
+        c.posterior_log_variance_clipped = self.posterior_log_variance_clipped.data_ptr()
+        return c
+
+    def ddpm_step(self, x, eps, t, noise=None, clip_denoised=True, out=None, seed=0, offset=0):
+        """x_{t-1} from (x_t, eps, noise) in one HIP kernel.  noise=None draws Philox noise in-kernel."""
+        if not x.is_cuda:
+            raise _lib.VdmiError("ddpm_step runs on the HIP device only")
+        x = x.contiguous()
+        eps = eps.to(torch.float32).contiguous()
+        out = torch.empty_like(x) if out is None else out
+        b = x.shape[0]
+        check(_lib.lib().vdmi_ddpm_step(
+            x.data_ptr(), eps.data_ptr(), None if noise is None else noise.contiguous().data_ptr(),
+            t.data_ptr(), C.byref(self._coefs()), out.data_ptr(), b, x.numel() // b, int(bool(clip_denoised)),
+            seed, offset, torch.cuda.current_stream().cuda_stream), "vdmi_ddpm_step")
+        return out
+
+    @torch.inference_mode()
+    def p_sample(self, x, t, frame_cond_features=None, clip_denoised=True, noise=None):
+        # reference: vdp.py:973-1002
+        predicted_noise = self.denoise_fn(x, t, frame_cond_features=frame_cond_features, null_frame_cond_prob=0.)
+        if clip_denoised and self.use_dynamic_thres:
+            # per-sample quantile threshold (off by default): elementwise torch expressions
+            x_recon = self._dynamic_clip(self.predict_start_from_noise(x, t=t, noise=predicted_noise))
+            model_mean, _, model_log_variance = self.q_posterior(x_start=x_recon, x_t=x, t=t)
+            noise = torch.randn_like(x) if noise is None else noise
+            nonzero_mask = (1 - (t == 0).float()).reshape(x.shape[0], *((1,) * (len(x.shape) - 1)))
+            return model_mean + nonzero_mask * (0.5 * model_log_variance).exp() * noise
+        if noise is None and self.noise_source == "torch":
+            noise = torch.randn_like(x)
+        seed = 0 if noise is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        return self.ddpm_step(x.to(torch.float32), predicted_noise, t, noise=noise, clip_denoised=clip_denoised,
+                              seed=seed)
+
+    # -- sampling loop ------------------------------------------------------------------------
+    def _graph_runner(self, shape, device):
+        """One denoise step (Unet3D plan + posterior kernel) captured in a HIP graph."""
+        from .modules import Unet3D
+        fn = self.denoise_fn
+        if not (self.use_hip_graph and isinstance(fn, Unet3D) and not fn.has_cond and not self.use_dynamic_thres):
+            return None
+        fn.engine().ensure_packed(device)
+        key = (tuple(shape), str(device), self.noise_source, fn.engine()._packed_key)
+        if key in self._graphs:
+            return self._graphs[key]
+        B, Cc, Fr, H, W = shape
+        plan = fn.engine().plan(B, Fr, H, W, device)
+        z = torch.zeros(shape, device=device, dtype=torch.float32) if self.noise_source == "torch" else None
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+        def step():
+            plan.run()
+            if z is not None:
+                z.normal_()
+            self.ddpm_step(plan.x_in, plan.eps_out, plan.t_in, noise=z, clip_denoised=True, out=plan.x_in, seed=seed)
+
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            saved = plan.x_in.clone()
+            step()                      # warm-up outside capture (sets kernel attributes, allocates)
+            plan.x_in.copy_(saved)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        runner = (graph, plan)
+        self._graphs[key] = runner
+        return runner
+
+    @torch.inference_mode()
+    def p_sample_loop(self, shape, x_T=None, noises=None):
+        """reference: vdp.py:1004-1014.  x_T / noises (one tensor per step, in execution order) may
+        be injected for parity checks; by default they are drawn as the reference draws them."""
+        device = self.betas.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
+        runner = self._graph_runner(shape, device) if noises is None else None
+        if runner is not None:
+            graph, plan = runner
+            plan.x_in.copy_(img)
+            for i in reversed(range(0, self.num_timesteps)):
+                plan.t_in.fill_(i)
+                graph.replay()
+            return plan.x_in.clone()
+        for k, i in enumerate(reversed(range(0, self.num_timesteps))):
+            t = torch.full((b,), i, device=device, dtype=torch.long)
+            img = self.p_sample(img, t, noise=None if noises is None else noises[k].to(device))
+        return img
+
+    @torch.inference_mode()
+    def sample(self, batch_size=16, prev_frames=None, frame_cond_scale=1.0):
+        # reference: vdp.py:1016-1089 (latent-space sampling + VAE decode)
+        device = next(self.denoise_fn.parameters()).device
+        latent_size = self.image_size // 8
+        latent_channels = self.vae.latent_dim
+        if exists(prev_frames) and exists(self.frame_cond_encoder):
+            raise NotImplementedError("frame-conditioned sampling (cross-attention to previous frames) is not built yet")
+        img = self.p_sample_loop((batch_size, latent_channels, self.num_frames, latent_size, latent_size))
+        self.vae.eval()
+        samples = self.vae.decode(img / self.latent_scale)
+        samples = samples.clamp(-1, 1)
+        return (samples + 1) / 2
+
+    def q_sample(self, x_start, t, noise=None):
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        return (extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start +
+                extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
+
+    def p_losses(self, x_start, t, prev_frames=None, noise=None, null_frame_cond_prob=0.,
+                 prob_focus_present=0., focus_present_mask=None):
+        # reference: vdp.py:1099-1163.  Forward value only: the HIP denoiser has no backward yet.
+        x_start_normalized = (x_start * 2.0 - 1.0).clamp(-1, 1)
+        self.vae.eval()
+        with torch.no_grad():
+            x_start_latent, _ = self.vae.encode(x_start_normalized)
+        x_start_latent = (x_start_latent * self.latent_scale).clamp(-10, 10)
+        if exists(prev_frames) and exists(self.frame_cond_encoder):
+            raise NotImplementedError("frame conditioning is not built yet")
+        noise = default(noise, lambda: torch.randn_like(x_start_latent))
+        x_noisy = self.q_sample(x_start=x_start_latent, t=t, noise=noise)
+        predicted_noise = self.denoise_fn(x_noisy, t, frame_cond_features=None,
+                                          null_frame_cond_prob=null_frame_cond_prob,
+                                          prob_focus_present=prob_focus_present,
+                                          focus_present_mask=focus_present_mask)
+        if self.loss_type == 'l1':
+            return F.l1_loss(noise, predicted_noise)
+        elif self.loss_type == 'l2':
+            return F.mse_loss(noise, predicted_noise)
+        raise NotImplementedError()
+
+    def forward(self, x, prev_frames=None, null_frame_cond_prob=0., *args, **kwargs):
+        b, device = x.shape[0], x.device
+        x = x.clamp(0, 1)
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+        return self.p_losses(x, t, prev_frames=prev_frames, null_frame_cond_prob=null_frame_cond_prob,
+                             *args, **kwargs)

@@ -1,0 +1,554 @@
+"""Execution plan of the Unet3D forward on MI355X.
+
+`UnetEngine` packs the module's parameters once into the layouts the HIP kernels stream
+(bf16 MFMA-fragment order, LayerNorm gammas folded into the following projection) and, per
+input shape, builds a `Plan`: a fixed list of C-ABI calls over preallocated channels-last
+bf16 activation buffers.  Running the plan is ~100 asynchronous launches on the current HIP
+stream with no host synchronisation, so a whole denoise step can be captured in a HIP graph.
+
+The order of operations follows the reference's Unet3D.forward
+(video_diffusion_pytorch/video_diffusion_pytorch.py:756-831 of the reference).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (EPI_NORM_SILU, EPI_PLAIN, EPI_QKV_ATTN, EPI_QKV_SLA, TapGemmArgs, TapPass, check)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def tile_for(epilogue: int, n: int) -> Tuple[int, int]:
+    bn, bkc = C.c_int(), C.c_int()
+    check(_lib.lib().vdmi_tapgemm_tile(epilogue, n, C.byref(bn), C.byref(bkc)), "vdmi_tapgemm_tile")
+    return bn.value, bkc.value
+
+
+class PackedTaps:
+    """Weights of one implicit-GEMM pass, packed on the host by vdmi_pack_taps."""
+
+    def __init__(self, w: torch.Tensor, cin0: int, cin1: int, epilogue: int, device, want_colsum=False):
+        # w: float32 [n][cin0+cin1][ntaps] on the CPU
+        w = w.detach().to(torch.float32).contiguous().cpu()
+        n, cin, ntaps = w.shape
+        assert cin == cin0 + cin1
+        self.n, self.ntaps, self.cin0, self.cin1 = n, ntaps, cin0, cin1
+        self.bn, self.bkc = tile_for(epilogue, n)
+        self.npad = (n + self.bn - 1) // self.bn * self.bn
+        lib = _lib.lib()
+        elems = lib.vdmi_pack_taps_elems(n, self.npad, cin0, cin1, ntaps, self.bkc)
+        out = torch.empty(elems, dtype=torch.int16)
+        colsum = torch.empty(n, dtype=torch.float32) if want_colsum else None
+        check(lib.vdmi_pack_taps(w.data_ptr(), n, self.npad, cin0, cin1, ntaps, self.bkc, out.data_ptr(),
+                                 _ptr(colsum)), "vdmi_pack_taps")
+        self.data = out.view(torch.bfloat16).to(device)
+        self.colsum = colsum.to(device) if want_colsum else None
+
+
+TAPS_3x3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+TAPS_4x4_S2 = [(ky - 1, kx - 1) for ky in range(4) for kx in range(4)]
+# transposed 4x4 / stride 2 / pad 1 conv, output parity p: (kernel index, input offset) pairs
+_UP_PAIRS = {0: [(1, 0), (3, -1)], 1: [(0, 1), (2, 0)]}
+
+
+def _fill_pass(p: TapPass, src0, c0, src1, c1, in_h, in_w, stride, taps, wdata, group_stride=0, group_frames=0):
+    p.src0, p.src1 = _ptr(src0), _ptr(src1)
+    p.c0, p.c1 = c0, c1
+    p.in_h, p.in_w, p.stride, p.ntaps = in_h, in_w, stride, len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        p.dy[i], p.dx[i] = dy, dx
+    p.w = _ptr(wdata)
+    p.w_group_stride, p.w_group_frames = group_stride, group_frames
+
+
+class _Call:
+    __slots__ = ("fn", "args", "name")
+
+    def __init__(self, fn, args, name):
+        self.fn, self.args, self.name = fn, args, name
+
+
+class Plan:
+    """All launches of one Unet3D forward for a fixed (B, F, H, W)."""
+
+    def __init__(self, eng: "UnetEngine", B: int, F: int, H: int, W: int, device):
+        self.eng, self.B, self.F, self.H, self.W, self.device = eng, B, F, H, W, device
+        self.calls: List[_Call] = []
+        self.keep: List[object] = []          # tensors / ctypes objects the calls point into
+        u = eng.unet
+        self.x_in = torch.zeros(B, u.channels, F, H, W, device=device, dtype=torch.float32)
+        self.t_in = torch.zeros(B, device=device, dtype=torch.int64)
+        self.cond_in = torch.zeros(B, u.cond_dim, device=device, dtype=torch.float32) if u.has_cond else None
+        self.null_mask = torch.zeros(B, device=device, dtype=torch.uint8) if u.has_cond else None
+        self.eps_out = torch.empty(B, u.out_dim, F, H, W, device=device, dtype=torch.float32)
+        self.taps: Dict[str, torch.Tensor] = {}   # named intermediate activations (for tests)
+        self._build()
+
+    # -- buffer / call helpers -------------------------------------------------------------
+    def _buf(self, rows: int, ch: int) -> torch.Tensor:
+        t = torch.empty(rows, ch, device=self.device, dtype=torch.bfloat16)
+        self.keep.append(t)
+        return t
+
+    def _add(self, fn, args, name):
+        self.calls.append(_Call(fn, args, name))
+
+    def _tapgemm(self, a: TapGemmArgs, name: str):
+        self.keep.append(a)
+        lib = _lib.lib()
+        self._add(lambda s, a=a: lib.vdmi_tapgemm(C.byref(a), s), None, name)
+
+    def _base_args(self, frames, grid_h, grid_w, out, n, epilogue, out_h=None, out_w=None) -> TapGemmArgs:
+        a = TapGemmArgs()
+        a.frames, a.frames_per_batch = frames, self.F
+        a.grid_h, a.grid_w = grid_h, grid_w
+        a.out_mul, a.out_off_y, a.out_off_x = 1, 0, 0
+        a.out_h, a.out_w = out_h or grid_h, out_w or grid_w
+        a.out, a.ldo, a.n, a.epilogue = _ptr(out), out.shape[1], n, epilogue
+        return a
+
+    # -- layer builders ---------------------------------------------------------------------
+    def _block(self, name, pk, srcs, h, w, gain, shift, bstride, res=None) -> torch.Tensor:
+        """Block: conv3x3 + RMSNorm + scale/shift + SiLU, optionally + residual (res_conv or identity)."""
+        frames = self.B * self.F
+        (s0, c0), (s1, c1) = srcs[0], (srcs[1] if len(srcs) > 1 else (None, 0))
+        w_pack, bias = pk
+        out = self._buf(frames * h * w, w_pack.n)
+        a = self._base_args(frames, h, w, out, w_pack.n, EPI_NORM_SILU)
+        _fill_pass(a.main, s0, c0, s1, c1, h, w, 1, TAPS_3x3, w_pack.data)
+        a.bias = _ptr(bias)
+        a.gain, a.shift = _ptr(gain), _ptr(shift)
+        a.gain_bstride = a.shift_bstride = bstride
+        a.norm_scale = float(w_pack.n) ** 0.5
+        if res is not None:
+            kind = res[0]
+            if kind == "conv":
+                _, rpack, rbias, rsrcs = res
+                (r0, rc0), (r1, rc1) = rsrcs[0], (rsrcs[1] if len(rsrcs) > 1 else (None, 0))
+                a.has_res = 1
+                _fill_pass(a.res, r0, rc0, r1, rc1, h, w, 1, [(0, 0)], rpack.data)
+                a.res_bias = _ptr(rbias)
+            else:
+                _, rt = res
+                a.has_res = 2
+                a.res_identity, a.ld_res = _ptr(rt), rt.shape[1]
+        self._tapgemm(a, name)
+        return out
+
+    def _resnet(self, name, rb, srcs, h, w) -> torch.Tensor:
+        """ResnetBlock (reference vdp.py:429-452)."""
+        if rb["ss_off"] is not None:
+            off = rb["ss_off"]
+            gain1 = self.gain[:, off:]
+            shift1 = self.shift[:, off:]
+            bstride = self.gain.shape[1]
+            g1, s1 = gain1, shift1
+        else:
+            g1, s1, bstride = rb["gamma1"], None, 0
+        hbuf = self._block(name + ".block1", (rb["w1"], rb["b1"]), srcs, h, w, g1, s1, bstride)
+        cmid = rb["w1"].n
+        if rb["wres"] is not None:
+            res = ("conv", rb["wres"], rb["bres"], srcs)
+        else:
+            res = ("identity", srcs[0][0])
+        return self._block(name + ".block2", (rb["w2"], rb["b2"]), [(hbuf, cmid)], h, w, rb["gamma2"], None, 0, res)
+
+    def _attention(self, name, at, x, c, h, w, temporal: bool) -> torch.Tensor:
+        """Residual(PreNorm(Attention)) over frames (temporal) or over the h*w positions (spatial)."""
+        lib = _lib.lib()
+        frames, hw = self.B * self.F, h * w
+        rows = frames * hw
+        hid = at["hid"]
+        qkv = self._buf(rows, 3 * hid)
+        a = self._base_args(frames, h, w, qkv, 3 * hid, EPI_QKV_ATTN)
+        _fill_pass(a.main, x, c, None, 0, h, w, 1, [(0, 0)], at["wqkv"].data)
+        a.colsum = _ptr(at["wqkv"].colsum)
+        a.ln_eps, a.q_scale = 1e-5, at["scale"]
+        if temporal:
+            a.rot_cos, a.rot_sin = _ptr(self.rot_cos), _ptr(self.rot_sin)
+            a.rot_frames, a.rot_hw = self.F, hw
+        self._tapgemm(a, name + ".qkv")
+        o = self._buf(rows, hid)
+        heads = hid // 32
+        if temporal:
+            n_tok, stride, bias = self.F, hw, self.pos_bias
+        else:
+            n_tok, stride, bias = hw, 1, None
+        self._add(lambda s, qkv=qkv, o=o, bias=bias: lib.vdmi_attn_core(
+            qkv.data_ptr(), o.data_ptr(), rows, heads, n_tok, stride, _ptr(bias), s), None, name + ".core")
+        y = self._buf(rows, c)
+        b = self._base_args(frames, h, w, y, c, EPI_PLAIN)
+        _fill_pass(b.main, o, hid, None, 0, h, w, 1, [(0, 0)], at["wout"].data)
+        b.has_res, b.res_identity, b.ld_res = 2, _ptr(x), c
+        self._tapgemm(b, name + ".out")
+        return y
+
+    def _sla(self, name, sl, x, c, h, w) -> torch.Tensor:
+        """Residual(PreNorm(SpatialLinearAttention)) (reference vdp.py:454-479) in two passes."""
+        lib = _lib.lib()
+        frames, hw = self.B * self.F, h * w
+        rows = frames * hw
+        hid = sl["hid"]
+        heads = hid // 32
+        qs = self._buf(rows, hid)
+        kvt = torch.empty(frames, 2 * hid, hw, device=self.device, dtype=torch.bfloat16)
+        self.keep.append(kvt)
+        a = self._base_args(frames, h, w, qs, 3 * hid, EPI_QKV_SLA)
+        _fill_pass(a.main, x, c, None, 0, h, w, 1, [(0, 0)], sl["wqkv"].data)
+        a.colsum = _ptr(sl["wqkv"].colsum)
+        a.ln_eps, a.q_scale = 1e-5, sl["scale"]
+        a.out2, a.sla_hw = _ptr(kvt), hw
+        self._tapgemm(a, name + ".qkv")
+        bn, bkc = tile_for(EPI_PLAIN, c)
+        cpad = (c + bn - 1) // bn * bn
+        wf = torch.zeros(frames, hid * cpad, device=self.device, dtype=torch.bfloat16)
+        self.keep.append(wf)
+        wout = sl["wout_f32"]
+        self._add(lambda s, kvt=kvt, wf=wf: lib.vdmi_sla_context(
+            kvt.data_ptr(), frames, heads, hw, wout.data_ptr(), c, cpad, bkc, wf.data_ptr(), s), None, name + ".ctx")
+        y = self._buf(rows, c)
+        b = self._base_args(frames, h, w, y, c, EPI_PLAIN)
+        _fill_pass(b.main, qs, hid, None, 0, h, w, 1, [(0, 0)], wf, group_stride=hid * cpad, group_frames=1)
+        b.bias = _ptr(sl["bout"])
+        b.has_res, b.res_identity, b.ld_res = 2, _ptr(x), c
+        self._tapgemm(b, name + ".out")
+        return y
+
+    def _down(self, name, dn, x, c, h, w) -> torch.Tensor:
+        frames = self.B * self.F
+        oh, ow = (h + 2 - 4) // 2 + 1, (w + 2 - 4) // 2 + 1
+        y = self._buf(frames * oh * ow, c)
+        a = self._base_args(frames, oh, ow, y, c, EPI_PLAIN)
+        _fill_pass(a.main, x, c, None, 0, h, w, 2, TAPS_4x4_S2, dn["w"].data)
+        a.bias = _ptr(dn["b"])
+        self._tapgemm(a, name)
+        return y
+
+    def _up(self, name, up, x, c, h, w) -> torch.Tensor:
+        frames = self.B * self.F
+        oh, ow = 2 * h, 2 * w
+        y = self._buf(frames * oh * ow, c)
+        for p in (0, 1):
+            for q in (0, 1):
+                taps = [(dy, dx) for (_, dy) in _UP_PAIRS[p] for (_, dx) in _UP_PAIRS[q]]
+                a = self._base_args(frames, h, w, y, c, EPI_PLAIN, out_h=oh, out_w=ow)
+                a.out_mul, a.out_off_y, a.out_off_x = 2, p, q
+                _fill_pass(a.main, x, c, None, 0, h, w, 1, taps, up["w"][p][q].data)
+                a.bias = _ptr(up["b"])
+                self._tapgemm(a, f"{name}.phase{p}{q}")
+        return y
+
+    # -- the forward graph ------------------------------------------------------------------
+    def _build(self):
+        eng, u = self.eng, self.eng.unet
+        lib = _lib.lib()
+        P = eng.packed
+        B, F, H, W = self.B, self.F, self.H, self.W
+        dev = self.device
+        frames = B * F
+        dims = u.dims
+
+        # constants that depend on F only
+        self.pos_bias = eng.pos_bias(F, dev)
+        self.rot_cos, self.rot_sin = eng.rotary_tables(F, dev)
+
+        # time / condition embedding -> per-block gain/shift tables
+        ed = P["emb_dim"]
+        self.emb_silu = torch.empty(B, ed, device=dev, dtype=torch.float32)
+        self.emb_raw = torch.empty(B, ed, device=dev, dtype=torch.float32)
+        half_total = P["half_total"]
+        self.gain = torch.empty(B, half_total, device=dev, dtype=torch.float32)
+        self.shift = torch.empty(B, half_total, device=dev, dtype=torch.float32)
+        tm = P["time"]
+        self._add(lambda s: lib.vdmi_time_embed(
+            self.t_in.data_ptr(), B, u.dim, tm["w1"].data_ptr(), tm["b1"].data_ptr(), tm["w2"].data_ptr(),
+            tm["b2"].data_ptr(), _ptr(self.cond_in), _ptr(P["null_cond"]), _ptr(self.null_mask),
+            u.cond_dim or 0, self.emb_silu.data_ptr(), self.emb_raw.data_ptr(), s), None, "time_embed")
+        self._add(lambda s: lib.vdmi_block_scale_shift(
+            self.emb_silu.data_ptr(), B, ed, P["w_all"].data_ptr(), P["b_all"].data_ptr(),
+            P["gamma_all"].data_ptr(), P["blk_off"].data_ptr(), P["blk_ch"].data_ptr(), P["nblocks"], half_total,
+            self.gain.data_ptr(), self.shift.data_ptr(), s), None, "block_scale_shift")
+
+        # init conv + init temporal attention
+        ic = P["init_conv"]
+        x = self._buf(frames * H * W, dims[0])
+        self._add(lambda s, x=x: lib.vdmi_init_conv(
+            self.x_in.data_ptr(), ic["w"].data_ptr(), ic["b"].data_ptr(), x.data_ptr(), B, u.channels, F, H, W,
+            dims[0], u.init_kernel_size, s), None, "init_conv")
+        self.taps["init_conv"] = x
+        x = self._attention("init_temporal_attn", P["init_temporal_attn"], x, dims[0], H, W, True)
+        self.taps["init_temporal_attn"] = x
+        r = x
+
+        h, w = H, W
+        skips = []
+        nres = len(dims) - 1
+        c = dims[0]
+        for i in range(nres):
+            L = P["downs"][i]
+            x = self._resnet(f"downs.{i}.0", L["rb0"], [(x, c)], h, w)
+            c = dims[i + 1]
+            x = self._resnet(f"downs.{i}.1", L["rb1"], [(x, c)], h, w)
+            if L["sla"] is not None:
+                x = self._sla(f"downs.{i}.2", L["sla"], x, c, h, w)
+            x = self._attention(f"downs.{i}.3", L["tattn"], x, c, h, w, True)
+            self.taps[f"downs.{i}"] = x
+            skips.append((x, c, h, w))
+            if L["down"] is not None:
+                x = self._down(f"downs.{i}.4", L["down"], x, c, h, w)
+                h, w = (h + 2 - 4) // 2 + 1, (w + 2 - 4) // 2 + 1
+
+        x = self._resnet("mid_block1", P["mid_block1"], [(x, c)], h, w)
+        x = self._attention("mid_spatial_attn", P["mid_spatial_attn"], x, c, h, w, False)
+        x = self._attention("mid_temporal_attn", P["mid_temporal_attn"], x, c, h, w, True)
+        x = self._resnet("mid_block2", P["mid_block2"], [(x, c)], h, w)
+        self.taps["mid"] = x
+
+        for i in range(nres):
+            L = P["ups"][i]
+            sk, sc, sh, sw = skips.pop()
+            if (sh, sw) != (h, w):
+                raise _lib.VdmiError(
+                    f"skip connection {sh}x{sw} does not match the upsampled map {h}x{w}: "
+                    "H and W must be divisible by 2**(levels-1)")
+            x = self._resnet(f"ups.{i}.0", L["rb0"], [(x, c), (sk, sc)], h, w)
+            c = L["rb0"]["w1"].n
+            x = self._resnet(f"ups.{i}.1", L["rb1"], [(x, c)], h, w)
+            if L["sla"] is not None:
+                x = self._sla(f"ups.{i}.2", L["sla"], x, c, h, w)
+            x = self._attention(f"ups.{i}.3", L["tattn"], x, c, h, w, True)
+            self.taps[f"ups.{i}"] = x
+            if L["up"] is not None:
+                x = self._up(f"ups.{i}.4", L["up"], x, c, h, w)
+                h, w = 2 * h, 2 * w
+
+        x = self._resnet("final_conv.0", P["final_rb"], [(x, c), (r, dims[0])], h, w)
+        self.taps["final_conv.0"] = x
+        fc = P["final_conv"]
+        self._add(lambda s, x=x: lib.vdmi_final_conv(
+            x.data_ptr(), fc["w"].data_ptr(), fc["b"].data_ptr(), self.eps_out.data_ptr(), B, u.dim, F, H, W,
+            u.out_dim, s), None, "final_conv.1")
+
+    def run(self):
+        """Enqueue every launch on the current stream (no synchronisation)."""
+        s = _stream()
+        for call in self.calls:
+            st = call.fn(s)
+            if st != 0:
+                check(st, call.name)
+
+
+class UnetEngine:
+    def __init__(self, unet):
+        self.unet = unet
+        self.packed = None
+        self._packed_key = None
+        self._plans: Dict[Tuple, Plan] = {}
+        self._const_cache: Dict[Tuple, object] = {}
+
+    # -- parameter packing -----------------------------------------------------------------
+    def _param_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.unet.parameters())
+
+    def ensure_packed(self, device):
+        key = self._param_key(device)
+        if key != self._packed_key:
+            self.packed = self._pack(device)
+            self._packed_key = key
+            self._plans.clear()
+            self._const_cache.clear()
+
+    @staticmethod
+    def _conv_w(w: torch.Tensor) -> torch.Tensor:
+        """Conv3d weight [n][cin][1][kh][kw] -> [n][cin][kh*kw] float32 (CPU)."""
+        n, cin = w.shape[0], w.shape[1]
+        return w.detach().float().cpu().reshape(n, cin, -1)
+
+    def _pack_resnet(self, rb, device, cin_split, stacked):
+        cin0, cin1 = cin_split
+        d = {}
+        d["w1"] = PackedTaps(self._conv_w(rb.block1.proj.weight), cin0, cin1, EPI_NORM_SILU, device)
+        d["b1"] = rb.block1.proj.bias.detach().float().to(device).contiguous()
+        cmid = d["w1"].n
+        d["w2"] = PackedTaps(self._conv_w(rb.block2.proj.weight), cmid, 0, EPI_NORM_SILU, device)
+        d["b2"] = rb.block2.proj.bias.detach().float().to(device).contiguous()
+        d["gamma1"] = rb.block1.norm.gamma.detach().float().reshape(-1).to(device).contiguous()
+        d["gamma2"] = rb.block2.norm.gamma.detach().float().reshape(-1).to(device).contiguous()
+        if isinstance(rb.res_conv, torch.nn.Conv3d):
+            d["wres"] = PackedTaps(self._conv_w(rb.res_conv.weight), cin0, cin1, EPI_NORM_SILU, device)
+            d["bres"] = rb.res_conv.bias.detach().float().to(device).contiguous()
+        else:
+            d["wres"], d["bres"] = None, None
+        if rb.mlp is not None:
+            d["ss_off"] = stacked["half"]
+            stacked["w"].append(rb.mlp[1].weight.detach().float().cpu())
+            stacked["b"].append(rb.mlp[1].bias.detach().float().cpu())
+            stacked["g"].append(rb.block1.norm.gamma.detach().float().reshape(-1).cpu())
+            stacked["off"].append(stacked["half"])
+            stacked["ch"].append(cmid)
+            stacked["half"] += cmid
+        else:
+            d["ss_off"] = None
+        return d
+
+    def _pack_attn(self, res_mod, device, dim_head):
+        """Residual(PreNorm(EinopsToAndFrom(Attention)))"""
+        pre = res_mod.fn
+        att = pre.fn.fn
+        gamma = pre.norm.gamma.detach().float().reshape(-1).cpu()
+        wq = att.to_qkv.weight.detach().float().cpu() * gamma[None, :]        # LayerNorm gamma folded in
+        hid = att.to_out.weight.shape[1]
+        return {
+            "wqkv": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_ATTN, device, want_colsum=True),
+            "wout": PackedTaps(att.to_out.weight.detach().float().cpu()[:, :, None], hid, 0, EPI_PLAIN, device),
+            "hid": hid,
+            "scale": float(dim_head) ** -0.5,
+        }
+
+    def _pack_sla(self, res_mod, device):
+        pre = res_mod.fn
+        sl = pre.fn
+        gamma = pre.norm.gamma.detach().float().reshape(-1).cpu()
+        wq = sl.to_qkv.weight.detach().float().cpu().reshape(sl.to_qkv.weight.shape[0], -1) * gamma[None, :]
+        hid = sl.to_out.weight.shape[1]
+        return {
+            "wqkv": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_SLA, device, want_colsum=True),
+            "wout_f32": sl.to_out.weight.detach().float().reshape(sl.to_out.weight.shape[0], -1).to(device).contiguous(),
+            "bout": sl.to_out.bias.detach().float().to(device).contiguous(),
+            "hid": hid,
+            "scale": float(sl.dim_head) ** -0.5,
+        }
+
+    def _pack_down(self, conv, device):
+        return {"w": PackedTaps(self._conv_w(conv.weight), conv.weight.shape[1], 0, EPI_PLAIN, device),
+                "b": conv.bias.detach().float().to(device).contiguous()}
+
+    def _pack_up(self, convt, device):
+        # ConvTranspose3d weight [cin][cout][1][4][4]; one 4-tap weight set per output parity (p, q)
+        w = convt.weight.detach().float().cpu()[:, :, 0]                     # [cin][cout][4][4]
+        cin = w.shape[0]
+        ws = [[None, None], [None, None]]
+        for p in (0, 1):
+            for q in (0, 1):
+                taps = [w[:, :, ky, kx].t() for (ky, _) in _UP_PAIRS[p] for (kx, _) in _UP_PAIRS[q]]   # each [cout][cin]
+                ws[p][q] = PackedTaps(torch.stack(taps, dim=-1), cin, 0, EPI_PLAIN, device)
+        return {"w": ws, "b": convt.bias.detach().float().to(device).contiguous()}
+
+    def _pack(self, device):
+        u = self.unet
+        for d_ in u.dims:
+            if d_ % 32:
+                raise _lib.VdmiError(f"channel widths must be multiples of 32 for the gfx950 kernels, got {u.dims}")
+        if u.attn_dim_head != 32:
+            raise _lib.VdmiError("the gfx950 attention kernels are built for attn_dim_head = 32")
+        f32 = lambda t: t.detach().float().to(device).contiguous()
+        P = {}
+        stacked = {"w": [], "b": [], "g": [], "off": [], "ch": [], "half": 0}
+        dims = u.dims
+        P["init_conv"] = {"w": f32(u.init_conv.weight[:, :, 0]), "b": f32(u.init_conv.bias)}
+        P["init_temporal_attn"] = self._pack_attn(u.init_temporal_attn, device, u.attn_dim_head)
+        P["time"] = {"w1": f32(u.time_mlp[1].weight), "b1": f32(u.time_mlp[1].bias),
+                     "w2": f32(u.time_mlp[3].weight), "b2": f32(u.time_mlp[3].bias)}
+        P["null_cond"] = f32(u.null_cond_emb.reshape(-1)) if u.has_cond else None
+        P["emb_dim"] = u.dim * 8 + (u.cond_dim or 0)
+
+        P["downs"] = []
+        for i, (b1, b2, sla, tat, down) in enumerate(u.downs):
+            L = {"rb0": self._pack_resnet(b1, device, (dims[i], 0), stacked),
+                 "rb1": self._pack_resnet(b2, device, (dims[i + 1], 0), stacked),
+                 "sla": self._pack_sla(sla, device) if u.use_sparse_linear_attn else None,
+                 "tattn": self._pack_attn(tat, device, u.attn_dim_head),
+                 "down": self._pack_down(down, device) if isinstance(down, torch.nn.Conv3d) else None}
+            P["downs"].append(L)
+        mid = dims[-1]
+        P["mid_block1"] = self._pack_resnet(u.mid_block1, device, (mid, 0), stacked)
+        P["mid_spatial_attn"] = self._pack_attn(u.mid_spatial_attn, device, 32)
+        P["mid_temporal_attn"] = self._pack_attn(u.mid_temporal_attn, device, u.attn_dim_head)
+        P["mid_block2"] = self._pack_resnet(u.mid_block2, device, (mid, 0), stacked)
+        P["ups"] = []
+        in_out = list(zip(dims[:-1], dims[1:]))
+        for i, ((dim_in, dim_out), (b1, b2, sla, tat, up)) in enumerate(zip(reversed(in_out), u.ups)):
+            L = {"rb0": self._pack_resnet(b1, device, (dim_out, dim_out), stacked),
+                 "rb1": self._pack_resnet(b2, device, (dim_in, 0), stacked),
+                 "sla": self._pack_sla(sla, device) if u.use_sparse_linear_attn else None,
+                 "tattn": self._pack_attn(tat, device, u.attn_dim_head),
+                 "up": self._pack_up(up, device) if isinstance(up, torch.nn.ConvTranspose3d) else None}
+            P["ups"].append(L)
+        P["final_rb"] = self._pack_resnet(u.final_conv[0], device, (dims[0], dims[0]), stacked)
+        fcw = u.final_conv[1].weight
+        P["final_conv"] = {"w": f32(fcw.reshape(fcw.shape[0], -1)), "b": f32(u.final_conv[1].bias)}
+
+        P["w_all"] = torch.cat(stacked["w"], 0).to(device).contiguous()
+        P["b_all"] = torch.cat(stacked["b"], 0).to(device).contiguous()
+        P["gamma_all"] = torch.cat(stacked["g"], 0).to(device).contiguous()
+        P["blk_off"] = torch.tensor(stacked["off"], dtype=torch.int32, device=device)
+        P["blk_ch"] = torch.tensor(stacked["ch"], dtype=torch.int32, device=device)
+        P["nblocks"] = len(stacked["off"])
+        P["half_total"] = stacked["half"]
+        return P
+
+    # -- small constants ---------------------------------------------------------------------
+    def pos_bias(self, nf: int, device) -> torch.Tensor:
+        """RelativePositionBias table [heads][F][F] (reference vdp.py:274-312): integer buckets from
+        the library's host routine, gathered from the embedding weight."""
+        key = ("pos_bias", nf)
+        if key not in self._const_cache:
+            rpb = self.unet.time_rel_pos_bias
+            buckets = np.empty((nf, nf), dtype=np.int32)
+            check(_lib.lib().vdmi_relpos_buckets(nf, rpb.num_buckets, rpb.max_distance, buckets.ctypes.data),
+                  "vdmi_relpos_buckets")
+            idx = torch.from_numpy(buckets.astype(np.int64)).to(device)
+            wt = rpb.relative_attention_bias.weight.detach().float().to(device)
+            self._const_cache[key] = wt[idx].permute(2, 0, 1).contiguous()
+        return self._const_cache[key]
+
+    def rotary_tables(self, nf: int, device):
+        """cos/sin of position * inv_freq, [F][16] float32 (half-split rotary, 32-dim heads)."""
+        key = ("rot", nf)
+        if key not in self._const_cache:
+            inv = self.unet.init_temporal_attn.fn.fn.fn.rotary_emb.inv_freq.detach().float().cpu()
+            ang = torch.arange(nf).float()[:, None] * inv[None, :]
+            self._const_cache[key] = (ang.cos().to(device).contiguous(), ang.sin().to(device).contiguous())
+        return self._const_cache[key]
+
+    # -- execution -------------------------------------------------------------------------------
+    def plan(self, B, F, H, W, device) -> Plan:
+        self.ensure_packed(device)
+        key = (B, F, H, W, str(device))
+        if key not in self._plans:
+            self._plans[key] = Plan(self, B, F, H, W, device)
+        return self._plans[key]
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, time: torch.Tensor, cond=None, null_cond_prob: float = 0.) -> torch.Tensor:
+        if not x.is_cuda:
+            raise _lib.VdmiError("Unet3D runs on the HIP device only (no CPU fallback); move the module and inputs to 'cuda'")
+        u = self.unet
+        B, Cc, F, H, W = x.shape
+        if Cc != u.channels:
+            raise ValueError(f"expected {u.channels} input channels, got {Cc}")
+        plan = self.plan(B, F, H, W, x.device)
+        plan.x_in.copy_(x.to(torch.float32))
+        plan.t_in.copy_(time.to(torch.int64))
+        if u.has_cond:
+            plan.cond_in.copy_(cond.to(torch.float32))
+            if null_cond_prob == 1:
+                plan.null_mask.fill_(1)
+            elif null_cond_prob == 0:
+                plan.null_mask.fill_(0)
+            else:   # prob_mask_like (reference vdp.py:68-74)
+                plan.null_mask.copy_((torch.rand(B, device=x.device) < null_cond_prob).to(torch.uint8))
+        plan.run()
+        return plan.eps_out.clone()

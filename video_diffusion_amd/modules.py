@@ -1,0 +1,326 @@
+"""Parameter containers with the reference's class names, constructor signatures and
+state-dict keys (``video_diffusion_pytorch/video_diffusion_pytorch.py:274-729`` of the
+reference).  They own ``nn.Parameter``s only; the arithmetic of the denoising path lives
+in the HIP library and is driven by :class:`video_diffusion_amd.engine.UnetEngine`.
+
+``Unet3D.forward`` is the drop-in for the reference's ``Unet3D.forward`` on the sampling
+path (no autograd, no frame cross-attention features, focus-present mask all False).
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+from torch import nn
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+def is_odd(n):
+    return (n % 2) == 1
+
+
+BERT_MODEL_DIM = 768   # text.py:9 of the reference
+
+
+class _HipOnly(nn.Module):
+    """Sub-blocks are parameter holders; they are executed fused, through Unet3D."""
+
+    def forward(self, *a, **k):   # pragma: no cover - guard
+        raise NotImplementedError(
+            f"{type(self).__name__} is executed inside the fused HIP pipeline; call Unet3D.forward")
+
+
+class RelativePositionBias(_HipOnly):
+    # reference: vdp.py:274-312
+    def __init__(self, heads=8, num_buckets=32, max_distance=128):
+        super().__init__()
+        self.num_buckets = num_buckets
+        self.max_distance = max_distance
+        self.relative_attention_bias = nn.Embedding(num_buckets, heads)
+
+
+class RotaryEmbedding(_HipOnly):
+    """Half-split rotary (the definition in the reference tree, video_diffusion_guidance.py:182-198).
+
+    The buffer name follows that definition; checkpoints written with the PyPI
+    ``rotary_embedding_torch`` carry a ``freqs`` parameter instead and need ``strict=False``.
+    """
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+        self.register_buffer("inv_freq", inv_freq)
+
+
+class Residual(_HipOnly):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+class SinusoidalPosEmb(_HipOnly):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+
+def Upsample(dim):
+    return nn.ConvTranspose3d(dim, dim, (1, 4, 4), (1, 2, 2), (0, 1, 1))
+
+
+def Downsample(dim):
+    return nn.Conv3d(dim, dim, (1, 4, 4), (1, 2, 2), (0, 1, 1))
+
+
+class LayerNorm(_HipOnly):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.gamma = nn.Parameter(torch.ones(1, dim, 1, 1, 1))
+
+
+class RMSNorm(_HipOnly):
+    def __init__(self, dim):
+        super().__init__()
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones(dim, 1, 1, 1))
+
+
+class PreNorm(_HipOnly):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = LayerNorm(dim)
+
+
+class Block(_HipOnly):
+    def __init__(self, dim, dim_out):
+        super().__init__()
+        self.proj = nn.Conv3d(dim, dim_out, (1, 3, 3), padding=(0, 1, 1))
+        self.norm = RMSNorm(dim_out)
+        self.act = nn.SiLU()
+
+
+class ResnetBlock(_HipOnly):
+    def __init__(self, dim, dim_out, *, time_emb_dim=None):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_emb_dim, dim_out * 2)) if exists(time_emb_dim) else None
+        self.block1 = Block(dim, dim_out)
+        self.block2 = Block(dim_out, dim_out)
+        self.res_conv = nn.Conv3d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
+
+
+class SpatialLinearAttention(_HipOnly):
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        hidden_dim = dim_head * heads
+        self.to_qkv = nn.Conv2d(dim, hidden_dim * 3, 1, bias=False)
+        self.to_out = nn.Conv2d(hidden_dim, dim, 1)
+
+
+class CrossAttention(_HipOnly):
+    # reference: vdp.py:480-528.  Only runs when frame_cond_features is passed, which
+    # p_sample_loop never does; the parameters exist so checkpoints load.
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner_dim = dim_head * heads
+        context_dim = default(context_dim, query_dim)
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
+        self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Linear(inner_dim, query_dim)
+
+
+class EinopsToAndFrom(_HipOnly):
+    def __init__(self, from_einops, to_einops, fn):
+        super().__init__()
+        self.from_einops = from_einops
+        self.to_einops = to_einops
+        self.fn = fn
+
+
+class Attention(_HipOnly):
+    def __init__(self, dim, heads=4, dim_head=32, rotary_emb=None):
+        super().__init__()
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        hidden_dim = dim_head * heads
+        self.rotary_emb = rotary_emb
+        self.to_qkv = nn.Linear(dim, hidden_dim * 3, bias=False)
+        self.to_out = nn.Linear(hidden_dim, dim, bias=False)
+
+
+class Unet3D(nn.Module):
+    """Same constructor and attribute tree as the reference (vdp.py:615-729)."""
+
+    def __init__(
+        self,
+        dim,
+        cond_dim=None,
+        out_dim=None,
+        dim_mults=(1, 2, 4, 8),
+        channels=4,
+        attn_heads=8,
+        attn_dim_head=32,
+        use_bert_text_cond=False,
+        init_dim=None,
+        init_kernel_size=7,
+        use_sparse_linear_attn=True,
+        block_type='resnet',
+        frame_cond_dim=512,
+    ):
+        super().__init__()
+        self.channels = channels
+        self.dim = dim
+        self.dim_mults = tuple(dim_mults)
+        self.attn_heads = attn_heads
+        self.attn_dim_head = attn_dim_head
+        self.init_kernel_size = init_kernel_size
+        self.use_sparse_linear_attn = use_sparse_linear_attn
+
+        rotary_emb = RotaryEmbedding(min(32, attn_dim_head))
+        temporal_attn = lambda dim: EinopsToAndFrom(
+            'b c f h w', 'b (h w) f c',
+            Attention(dim, heads=attn_heads, dim_head=attn_dim_head, rotary_emb=rotary_emb))
+
+        self.time_rel_pos_bias = RelativePositionBias(heads=attn_heads, max_distance=32)
+
+        init_dim = default(init_dim, dim)
+        assert is_odd(init_kernel_size)
+        init_padding = init_kernel_size // 2
+        self.init_conv = nn.Conv3d(channels, init_dim, (1, init_kernel_size, init_kernel_size),
+                                   padding=(0, init_padding, init_padding))
+        self.init_temporal_attn = Residual(PreNorm(init_dim, temporal_attn(init_dim)))
+
+        dims = [init_dim, *map(lambda m: dim * m, dim_mults)]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        self.dims = dims
+
+        time_dim = dim * 8
+        self.time_mlp = nn.Sequential(
+            SinusoidalPosEmb(dim),
+            nn.Linear(dim, time_dim),
+            nn.GELU(),
+            nn.Linear(time_dim, time_dim),
+        )
+
+        self.has_cond = exists(cond_dim) or use_bert_text_cond
+        cond_dim = BERT_MODEL_DIM if use_bert_text_cond else cond_dim
+        self.cond_dim = cond_dim if self.has_cond else None
+        self.null_cond_emb = nn.Parameter(torch.randn(1, cond_dim)) if self.has_cond else None
+
+        self.has_frame_cross_attn = exists(frame_cond_dim)
+        if self.has_frame_cross_attn:
+            self.frame_cross_attns_down = nn.ModuleList([])
+            self.frame_cross_attns_up = nn.ModuleList([])
+            for dim_out in dims[1:]:
+                self.frame_cross_attns_down.append(
+                    Residual(PreNorm(dim_out, CrossAttention(dim_out, context_dim=frame_cond_dim,
+                                                             heads=attn_heads, dim_head=attn_dim_head))))
+            for dim_in in reversed(dims[:-1]):
+                self.frame_cross_attns_up.append(
+                    Residual(PreNorm(dim_in, CrossAttention(dim_in, context_dim=frame_cond_dim,
+                                                            heads=attn_heads, dim_head=attn_dim_head))))
+
+        cond_dim = time_dim + int(cond_dim or 0)
+
+        self.downs = nn.ModuleList([])
+        self.ups = nn.ModuleList([])
+        num_resolutions = len(in_out)
+
+        block_klass = ResnetBlock
+        block_klass_cond = partial(block_klass, time_emb_dim=cond_dim)
+
+        for ind, (dim_in, dim_out) in enumerate(in_out):
+            is_last = ind >= (num_resolutions - 1)
+            self.downs.append(nn.ModuleList([
+                block_klass_cond(dim_in, dim_out),
+                block_klass_cond(dim_out, dim_out),
+                Residual(PreNorm(dim_out, SpatialLinearAttention(dim_out, heads=attn_heads)))
+                if use_sparse_linear_attn else nn.Identity(),
+                Residual(PreNorm(dim_out, temporal_attn(dim_out))),
+                Downsample(dim_out) if not is_last else nn.Identity(),
+            ]))
+
+        mid_dim = dims[-1]
+        self.mid_block1 = block_klass_cond(mid_dim, mid_dim)
+        spatial_attn = EinopsToAndFrom('b c f h w', 'b f (h w) c', Attention(mid_dim, heads=attn_heads))
+        self.mid_spatial_attn = Residual(PreNorm(mid_dim, spatial_attn))
+        self.mid_temporal_attn = Residual(PreNorm(mid_dim, temporal_attn(mid_dim)))
+        self.mid_block2 = block_klass_cond(mid_dim, mid_dim)
+
+        for ind, (dim_in, dim_out) in enumerate(reversed(in_out)):
+            is_last = ind >= (num_resolutions - 1)
+            self.ups.append(nn.ModuleList([
+                block_klass_cond(dim_out * 2, dim_in),
+                block_klass_cond(dim_in, dim_in),
+                Residual(PreNorm(dim_in, SpatialLinearAttention(dim_in, heads=attn_heads)))
+                if use_sparse_linear_attn else nn.Identity(),
+                Residual(PreNorm(dim_in, temporal_attn(dim_in))),
+                Upsample(dim_in) if not is_last else nn.Identity(),
+            ]))
+
+        out_dim = default(out_dim, channels)
+        self.out_dim = out_dim
+        self.final_conv = nn.Sequential(block_klass(dim * 2, dim), nn.Conv3d(dim, out_dim, 1))
+
+        self._engine = None
+
+    # -- execution ---------------------------------------------------------------
+    def engine(self):
+        """The HIP execution plan bound to this module's parameters (built lazily)."""
+        if self._engine is None:
+            from .engine import UnetEngine
+            object.__setattr__(self, "_engine", UnetEngine(self))
+        return self._engine
+
+    def forward_with_cond_scale(self, *args, cond_scale=2., frame_cond_scale=1., **kwargs):
+        # reference: vdp.py:731-754
+        logits = self.forward(*args, null_cond_prob=0., null_frame_cond_prob=0., **kwargs)
+        if cond_scale == 1 and frame_cond_scale == 1:
+            return logits
+        if self.has_cond and cond_scale != 1:
+            null_logits = self.forward(*args, null_cond_prob=1., null_frame_cond_prob=0., **kwargs)
+            logits = null_logits + (logits - null_logits) * cond_scale
+        if self.has_frame_cross_attn and frame_cond_scale != 1:
+            null_frame_logits = self.forward(*args, null_cond_prob=0., null_frame_cond_prob=1., **kwargs)
+            logits = null_frame_logits + (logits - null_frame_logits) * frame_cond_scale
+        return logits
+
+    def forward(
+        self,
+        x,
+        time,
+        cond=None,
+        null_cond_prob=0.,
+        frame_cond_features=None,
+        null_frame_cond_prob=0.,
+        focus_present_mask=None,
+        prob_focus_present=0.,
+    ):
+        # reference: vdp.py:756-831
+        assert not (self.has_cond and not exists(cond)), 'cond must be passed in if cond_dim specified'
+        if exists(frame_cond_features):
+            raise NotImplementedError(
+                "frame cross-attention conditioning is not on the p_sample_loop path and is not built yet")
+        if exists(focus_present_mask) or prob_focus_present != 0.:
+            raise NotImplementedError("focus-present masking (training-time feature) is not built yet")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
+            raise NotImplementedError("the HIP denoiser is forward-only; backward is not built yet")
+        return self.engine().forward(x, time, cond=cond, null_cond_prob=null_cond_prob)
