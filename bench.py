@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DDPM sampling throughput of the Moving-MNIST-shape model on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one denoise step (Unet3D forward + posterior update) over the local batch, replayed
+as one captured HIP graph.  Workload at every N: BASELINE.json configs[1] per GPU — Unet3D(dim=64,
+dim_mults=(1,2,4,8), channels=1), x = (16, 1, 10, 64, 64), bf16 kernels / fp32 sampler state,
+GaussianDiffusion(timesteps=1000), random-init weights, synthetic noise input.  The batch is
+sharded by sample (weak scaling: 16 videos per GPU); the only collective is the all-gather of the
+finished videos, timed separately.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X
+PEAK_HBM_GBS = 8000.0
+
+CFG1 = dict(dim=64, dim_mults=(1, 2, 4, 8), channels=1)
+FRAMES, SIZE, TIMESTEPS = 10, 64, 1000
+
+
+def cpu_baseline(batch, steps):
+    """The CPU oracle (fp32 restatement of the reference path) on the host cores, bounded sample."""
+    from oracle import vdm_oracle as O
+    from video_diffusion_amd import Unet3D
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = Unet3D(**CFG1)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    cfg = O.UnetCfg(dim=64, dim_mults=(1, 2, 4, 8), channels=1)
+    bufs = O.diffusion_buffers(TIMESTEPS)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(batch, 1, FRAMES, SIZE, SIZE, generator=g)
+    with torch.no_grad():
+        def one(i, x):
+            t = torch.full((batch,), TIMESTEPS - 1 - i, dtype=torch.long)
+            eps = O.unet3d_forward(sd, cfg, x, t)
+            return O.p_sample_step(bufs, x, t, eps, torch.randn(x.shape, generator=g))
+        x = one(0, x)                      # warm-up
+        t0 = time.perf_counter()
+        for i in range(steps):
+            x = one(i + 1, x)
+        dt = time.perf_counter() - t0
+    steps_per_s = steps / dt
+    return {"value": batch * steps_per_s / TIMESTEPS, "unit": "videos/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} denoise steps at batch {batch} of the same model/shape, fp32, torch CPU "
+                      f"({dt:.1f} s); videos/s = batch*steps/s/{TIMESTEPS}",
+            "denoise_steps_per_s": steps_per_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="videos per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch through `python -m torch.distributed.run --nproc-per-node N`")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from video_diffusion_amd import GaussianDiffusion, Unet3D
+    from video_diffusion_amd.parallel import gather_videos
+
+    torch.manual_seed(0)
+    unet = Unet3D(**CFG1).to(device).eval()
+    gd = GaussianDiffusion(unet, torch.nn.Identity(), image_size=SIZE, num_frames=FRAMES, channels=1,
+                           timesteps=TIMESTEPS).to(device)
+    gd.noise_source = "philox"
+    B = args.batch
+    shape = (B, 1, FRAMES, SIZE, SIZE)
+    torch.manual_seed(1234 + rank)
+
+    graph, plan = gd._graph_runner(shape, device)
+    plan.x_in.copy_(torch.randn(shape, device=device))
+    seed = 99 + rank
+
+    def eager_step():
+        plan.run()
+        gd.ddpm_step(plan.x_in, plan.eps_out, plan.t_in, noise=None, clip_denoised=True, out=plan.x_in, seed=seed)
+
+    def step(i):
+        plan.t_in.fill_(TIMESTEPS - 1 - (i % TIMESTEPS))
+        if args.no_graph:
+            eager_step()
+        else:
+            graph.replay()
+
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(plan.x_in).all(), "sampler state went non-finite"
+
+    # the one collective of the sharded sampler: all-gather of the finished videos
+    gather_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        full = gather_videos(plan.x_in, B * world)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        assert full.shape[0] == B * world
+
+    # ---- per-kernel timing with HIP events on the launch stream (eager, same kernels, same data) ----
+    per_call = {}
+    if rank == 0:
+        stream = torch.cuda.current_stream()
+        reps = max(3, min(args.steps, 10))
+        evs = []
+        for r in range(reps):
+            plan.t_in.fill_(TIMESTEPS - 1 - r)
+            s = stream.cuda_stream
+            for call in plan.calls:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                st = call.fn(s)
+                e1.record(stream)
+                assert st == 0, call.name
+                evs.append((call, e0, e1))
+        torch.cuda.synchronize()
+        for call, e0, e1 in evs:
+            d = per_call.setdefault(call.name, {"ms": 0.0, "n": 0, "meta": call.args})
+            d["ms"] += e0.elapsed_time(e1)
+            d["n"] += 1
+        classes = {}
+        for name, d in per_call.items():
+            meta = d["meta"] or {}
+            key = meta.get("kernel", name.split(".")[-1] if not name.startswith(("time", "block", "init", "final")) else name)
+            c = classes.setdefault(key, {"ms_per_step": 0.0, "launches_per_step": 0, "flops_per_step": 0.0,
+                                         "bytes_per_step": 0.0})
+            c["ms_per_step"] += d["ms"] / reps
+            c["launches_per_step"] += d["n"] // reps
+            c["flops_per_step"] += meta.get("flops", 0.0)
+            c["bytes_per_step"] += meta.get("bytes", 0.0)
+        dom_key = max(classes, key=lambda k: classes[k]["ms_per_step"])
+        dom = classes[dom_key]
+        avg_ms = dom["ms_per_step"] / dom["launches_per_step"]
+        achieved = dom["flops_per_step"] / (dom["ms_per_step"] * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom_key)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": dom_key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": dom["launches_per_step"],
+                    "algorithmic_gflop_per_launch": round(dom["flops_per_step"] / dom["launches_per_step"] / 1e9, 2)}
+        breakdown = {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches": v["launches_per_step"],
+                         "tflops": round(v["flops_per_step"] / (v["ms_per_step"] * 1e-3) / 1e12, 1) if v["flops_per_step"] else None,
+                         "alg_gbs": round(v["bytes_per_step"] / (v["ms_per_step"] * 1e-3) / 1e9, 1) if v["bytes_per_step"] else None}
+                     for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+
+    if rank == 0:
+        steps_per_s = args.steps / elapsed
+        videos_per_s = B * world * steps_per_s / TIMESTEPS
+        out = {
+            "metric": "sampled videos/sec + denoise steps/sec, 10x64x64 MovingMNIST, 1/2/4/8 MI355X",
+            "value": round(videos_per_s, 4), "unit": "videos/s (T=1000 DDPM steps per video)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Unet3D(dim=64,dim_mults=(1,2,4,8),channels=1), "
+                                   "p_sample over x=(16,1,10,64,64) per GPU, T=1000, random-init weights",
+                       "batch_per_gpu": B, "global_batch": B * world, "timesteps": TIMESTEPS,
+                       "launch": "eager" if args.no_graph else "hip-graph replay",
+                       "parallelism": f"batch-shard x{world}, all-gather of finished videos"},
+            "denoise_steps_per_s": round(steps_per_s, 3),
+            "sample_steps_per_s": round(B * world * steps_per_s, 2),
+            "model_tflops": round(154.5e9 * B * world * steps_per_s / 1e12, 1),
+            "allgather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "roofline": roofline, "breakdown_ms_per_step": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch=4, steps=10)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

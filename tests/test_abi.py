@@ -1,0 +1,91 @@
+"""CPU: the C-ABI library loads, exports every symbol include/vdmi.h declares, and its host-side
+routines (weight packing, relative-position buckets, status strings) behave.  No GPU launches."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import golden
+from video_diffusion_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vdmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vdmi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS)
+    assert lib.vdmi_version() >= 100
+    assert lib.vdmi_strerror(0) == b"ok"
+    assert b"shape" in lib.vdmi_strerror(-2)
+
+
+def test_relpos_buckets_match_reference():
+    lib = _lib.lib()
+    g = golden("relpos_buckets")
+    for k, v in g.items():
+        _, md, n = k.split("_")
+        n, md = int(n[1:]), int(md[2:])
+        out = np.empty((n, n), dtype=np.int32)
+        assert lib.vdmi_relpos_buckets(n, 32, md, out.ctypes.data) == 0
+        assert np.array_equal(out, v.numpy().astype(np.int32)), k
+
+
+def _bf16(x):
+    return torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize("n,cin0,cin1,ntaps,bkc", [(32, 32, 0, 9, 64), (64, 64, 64, 1, 64), (96, 40, 24, 4, 32)])
+def test_pack_taps_layout(n, cin0, cin1, ntaps, bkc):
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    cin = cin0 + cin1
+    w = rng.standard_normal((n, cin, ntaps)).astype(np.float32)
+    npad = (n + 63) // 64 * 64
+    elems = lib.vdmi_pack_taps_elems(n, npad, cin0, cin1, ntaps, bkc)
+    out = np.zeros(elems, dtype=np.uint16)
+    colsum = np.zeros(n, dtype=np.float32)
+    assert lib.vdmi_pack_taps(w.ctypes.data, n, npad, cin0, cin1, ntaps, bkc, out.ctypes.data, colsum.ctypes.data) == 0
+    nch0, nch1 = -(-cin0 // bkc), -(-cin1 // bkc)
+    assert elems == (nch0 + nch1) * ntaps * npad * bkc
+    packed = torch.from_numpy(out.view(np.int16)).view(torch.bfloat16).float().numpy()
+    packed = packed.reshape(nch0 + nch1, ntaps, npad // 32, bkc // 16, 64, 8)
+    wb = _bf16(w)
+    for c in range(nch0 + nch1):
+        first = c < nch0
+        cbase, clim, coff = (c * bkc, cin0, 0) if first else ((c - nch0) * bkc, cin1, cin0)
+        for lane in (0, 5, 31, 32, 63):
+            for ks in range(bkc // 16):
+                for j in (0, 7):
+                    for ct in range(npad // 32):
+                        co, ci = ct * 32 + (lane & 31), cbase + ks * 16 + 8 * (lane >> 5) + j
+                        for t in range(ntaps):
+                            want = wb[co, coff + ci, t] if (co < n and ci < clim) else 0.0
+                            assert packed[c, t, ct, ks, lane, j] == want
+    assert np.allclose(colsum, wb.sum(axis=(1, 2)), rtol=1e-5, atol=1e-5)
+
+
+def test_bad_arguments_are_rejected_without_launching():
+    lib = _lib.lib()
+    assert lib.vdmi_tapgemm(None, None) == -1
+    a = _lib.TapGemmArgs()
+    assert lib.vdmi_tapgemm(C.byref(a), None) == -1           # null output
+    assert lib.vdmi_attn_core(None, None, 0, 8, 10, 1, None, None) == -1
+    assert lib.vdmi_ddpm_step(None, None, None, None, None, None, 1, 1, 1, 0, 0, None) == -1
+    bn, bkc = C.c_int(), C.c_int()
+    assert lib.vdmi_tapgemm_tile(_lib.EPI_NORM_SILU, 64, C.byref(bn), C.byref(bkc)) == 0 and bn.value == 64
+    assert lib.vdmi_tapgemm_tile(_lib.EPI_NORM_SILU, 4096, C.byref(bn), C.byref(bkc)) == -2
+    with pytest.raises(_lib.VdmiError):
+        _lib.check(-2, "probe")

@@ -83,7 +83,7 @@ class _Call:
 class Plan:
     """All launches of one Unet3D forward for a fixed (B, F, H, W)."""
 
-    def __init__(self, eng: "UnetEngine", B: int, F: int, H: int, W: int, device):
+    def __init__(self, eng: "UnetEngine", B: int, F: int, H: int, W: int, device, build: bool = True):
         self.eng, self.B, self.F, self.H, self.W, self.device = eng, B, F, H, W, device
         self.calls: List[_Call] = []
         self.keep: List[object] = []          # tensors / ctypes objects the calls point into
@@ -94,7 +94,9 @@ class Plan:
         self.null_mask = torch.zeros(B, device=device, dtype=torch.uint8) if u.has_cond else None
         self.eps_out = torch.empty(B, u.out_dim, F, H, W, device=device, dtype=torch.float32)
         self.taps: Dict[str, torch.Tensor] = {}   # named intermediate activations (for tests)
-        self._build()
+        self._setup()
+        if build:
+            self._build()
 
     # -- buffer / call helpers -------------------------------------------------------------
     def _buf(self, rows: int, ch: int) -> torch.Tensor:
@@ -108,7 +110,14 @@ class Plan:
     def _tapgemm(self, a: TapGemmArgs, name: str):
         self.keep.append(a)
         lib = _lib.lib()
-        self._add(lambda s, a=a: lib.vdmi_tapgemm(C.byref(a), s), None, name)
+        # algorithmic work of the launch: 2*M*N*K over the positions computed (main pass + fused 1x1 pass)
+        m = a.frames * a.grid_h * a.grid_w
+        k = (a.main.c0 + a.main.c1) * a.main.ntaps + ((a.res.c0 + a.res.c1) if a.has_res == 1 else 0)
+        bn, _ = tile_for(a.epilogue, a.n)
+        in_rows = a.frames * a.main.in_h * a.main.in_w
+        meta = {"kernel": f"tapgemm<epi={a.epilogue},bn={bn}>", "flops": 2.0 * m * a.n * k,
+                "bytes": 2.0 * (in_rows * (a.main.c0 + a.main.c1) + m * a.n + a.n * k)}
+        self._add(lambda s, a=a: lib.vdmi_tapgemm(C.byref(a), s), meta, name)
 
     def _base_args(self, frames, grid_h, grid_w, out, n, epilogue, out_h=None, out_w=None) -> TapGemmArgs:
         a = TapGemmArgs()
@@ -251,14 +260,13 @@ class Plan:
         return y
 
     # -- the forward graph ------------------------------------------------------------------
-    def _build(self):
+    def _setup(self):
+        """Constants and the time/condition embedding launches (everything the layers share)."""
         eng, u = self.eng, self.eng.unet
         lib = _lib.lib()
         P = eng.packed
-        B, F, H, W = self.B, self.F, self.H, self.W
+        B, F = self.B, self.F
         dev = self.device
-        frames = B * F
-        dims = u.dims
 
         # constants that depend on F only
         self.pos_bias = eng.pos_bias(F, dev)
@@ -280,6 +288,14 @@ class Plan:
             self.emb_silu.data_ptr(), B, ed, P["w_all"].data_ptr(), P["b_all"].data_ptr(),
             P["gamma_all"].data_ptr(), P["blk_off"].data_ptr(), P["blk_ch"].data_ptr(), P["nblocks"], half_total,
             self.gain.data_ptr(), self.shift.data_ptr(), s), None, "block_scale_shift")
+
+    def _build(self):
+        eng, u = self.eng, self.eng.unet
+        lib = _lib.lib()
+        P = eng.packed
+        B, F, H, W = self.B, self.F, self.H, self.W
+        frames = B * F
+        dims = u.dims
 
         # init conv + init temporal attention
         ic = P["init_conv"]
