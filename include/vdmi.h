@@ -143,6 +143,20 @@ int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int heads, int n_to
                    const float* bias, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused temporal attention: Residual(PreNorm(EinopsToAndFrom('b c f h w','b (h w) f c', Attention)))
+ * of the reference in one kernel (vdp.py:331-337, 380-408, 531-612, 636): channel LayerNorm, to_qkv,
+ * q scaling, rotary, q.k^T + relative-position bias, softmax over the f frames of each site, .v,
+ * to_out and the residual add.  x, y: bf16 [b*f*hw][c] (y may not alias x); c in {32, 64, 128},
+ * f <= 32, dim_head 32.  wpack: vdmi_pack_tattn output.  bias: float [heads][f][f] or NULL;
+ * rot_cos/rot_sin: float [f][16] or NULL (no rotary).
+ * ------------------------------------------------------------------------------------------ */
+size_t vdmi_pack_tattn_elems(int c, int heads);                                           /* HOST */
+int vdmi_pack_tattn(const float* wqkv_gamma_folded, const float* wout, int c, int heads, uint16_t* out);  /* HOST */
+int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const float* bias, const float* rot_cos,
+                     const float* rot_sin, int b, int f, int hw, int c, int heads, float q_scale, float eps,
+                     vdmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * SpatialLinearAttention pass 1 (vdp.py:471-476): per (frame, head) softmax of k over the
  * n = H*W positions, context = k·vᵀ (32x32), folded into the output projection:
  *   W'[frame][c][h*32+d] = sum_e to_out.weight[c][h*32+e] * context[h][d][e]

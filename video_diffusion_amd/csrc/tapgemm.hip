@@ -183,7 +183,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
 }
 
 template <int BM, int BN, int WM, int WN, int BKC, int EPI>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void tapgemm_kernel(const KArgs a) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(const KArgs a) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];

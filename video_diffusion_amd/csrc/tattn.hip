@@ -1,0 +1,321 @@
+// Fused temporal attention for gfx950: Residual(PreNorm(Attention over frames)) in ONE kernel,
+// activations never leave registers.
+//
+// Unit of work: a "group" of 32 rows = floor(32 / F) spatial sites x F frames (+ padding rows).
+// One wave owns one group.  With v_mfma_f32_32x32x16_bf16 a 32x32 accumulator holds its column
+// on the lane and its 16 rows in registers; a product that contracts over the accumulator's ROW
+// index can take the accumulator registers directly as its 8-element operand fragments
+// (registers 8s..8s+7 for k-step s), in whatever row order they are in, provided the other
+// operand uses the same order.  The chain below is arranged so that every product contracts over
+// the previous accumulator's row index:
+//
+//   x (rows on lanes, channels in fragments)  -- LayerNorm in registers -->  xh
+//   Q^T, K^T [d x row]   = Wq/Wk (A) * xh (B)          rows on lanes, d in registers
+//   V   [row x d]        = xh (A) * Wv (B)             d on lanes, rows in registers
+//   S^T [key x query]    = K^T regs (A) * Q^T regs (B) contraction over d
+//   P^T = softmax over keys (registers + one cross-half shuffle), block-diagonal site mask, bias
+//   O^T [d x query]      = V regs (A) * P^T regs (B)   contraction over keys
+//   Y^T [c x query]     += Wout_h (A, k permuted to the register order) * O^T regs (B)
+//
+// Output channels are permuted (through Wout's row order) so that a lane ends up with 8
+// consecutive channels per register pair: 16-byte stores, and the residual x is re-read with the
+// same 16-byte pattern.  Weights are the only LDS traffic: one head's slice, double buffered.
+#include "vdmi_common.h"
+#include <cstring>
+
+namespace {
+
+struct TAttnArgs {
+    const __bf16* x;
+    __bf16* y;
+    const __bf16* w;        // [heads][3*KS + 2*CT][64][8]
+    const float* bias;      // [heads][F][F] or null
+    const float* rot_cos;   // [F][16] or null
+    const float* rot_sin;
+    int F, HW, heads;
+    int sites_per_group;    // floor(32 / F)
+    int groups_per_sample;  // ceil(HW / sites_per_group): groups never straddle samples, so a sample's
+                            // result does not depend on what else is in the batch
+    int ngroups;            // B * groups_per_sample
+    float q_scale, eps;
+};
+
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = f2bf(a[8 * s + j]);
+    return f;
+}
+
+template <int C>
+__global__ __launch_bounds__(512, 2) void tattn_fused_kernel(const TAttnArgs a) {
+    constexpr int KS = C / 16, CT = C / 32, NFRAG = 3 * KS + 2 * CT, SLICE = NFRAG * 512;
+    constexpr int WP = (SLICE / 8 + 511) / 512;          // 16-byte pieces per thread per slice
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* wbuf = reinterpret_cast<__bf16*>(smem);      // [2][SLICE]
+    float* biasl = reinterpret_cast<float*>(smem + 2 * SLICE * 2);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int F = a.F, g = a.sites_per_group;
+
+    for (int i = tid; i < a.heads * F * F; i += 512) biasl[i] = a.bias ? a.bias[i] : 0.f;
+
+    // per-lane constants: this lane's row as a query / row of x, and the 16 key rows of its registers
+    const int q_site = l31 / F, q_f = l31 - q_site * F;
+    int kf[16];
+    unsigned kmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, half), ks = row / F;
+        kf[r] = row - ks * F;
+        if (ks == q_site && ks < g) kmask |= 1u << r;
+    }
+    f32x4 rc[2], rs[2];
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+        if (a.rot_cos) {
+            rc[rg] = *reinterpret_cast<const f32x4*>(a.rot_cos + q_f * 16 + 8 * rg + 4 * half);
+            rs[rg] = *reinterpret_cast<const f32x4*>(a.rot_sin + q_f * 16 + 8 * rg + 4 * half);
+        } else {
+            rc[rg] = f32x4{1.f, 1.f, 1.f, 1.f};
+            rs[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    bf16x8 wreg[WP];
+    auto load_slice = [&](int head) {
+        const __bf16* p = a.w + (long long)head * SLICE;
+#pragma unroll
+        for (int k = 0; k < WP; ++k) {
+            const int idx = tid + k * 512;
+            if (idx * 8 < SLICE) wreg[k] = *reinterpret_cast<const bf16x8*>(p + idx * 8);
+        }
+    };
+    auto store_slice = [&](__bf16* dst) {
+#pragma unroll
+        for (int k = 0; k < WP; ++k) {
+            const int idx = tid + k * 512;
+            if (idx * 8 < SLICE) *reinterpret_cast<bf16x8*>(dst + idx * 8) = wreg[k];
+        }
+    };
+
+    const int rounds = (a.ngroups + 7) / 8;
+    int step = 0;   // counts head iterations over the whole kernel (buffer parity)
+    load_slice(0);
+    for (int round = blockIdx.x; round < rounds; round += gridDim.x) {
+        const int grp = round * 8 + wave;
+        const int b = grp / a.groups_per_sample;
+        const int s = (grp - b * a.groups_per_sample) * g + q_site;      // site within the sample
+        const bool rowvalid = grp < a.ngroups && q_site < g && s < a.HW;
+        const long long grow = rowvalid ? ((long long)b * F + q_f) * a.HW + s : 0;
+        // ---- load this lane's row (8*KS values) and LayerNorm it in registers -------------------
+        bf16x8 xh[KS];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (rowvalid) v = *reinterpret_cast<const bf16x8*>(a.x + grow * C + ks * 16 + 8 * half);
+            xh[ks] = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
+        }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const float mean = s1 * (1.0f / C);
+        const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xh[ks][e] = f2bf(((float)xh[ks][e] - mean) * rstd);
+
+        f32x16 oacc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[ct][r] = 0.f;
+
+        for (int head = 0; head < a.heads; ++head, ++step) {
+            __bf16* wb = wbuf + (step & 1) * SLICE;
+            store_slice(wb);
+            __syncthreads();
+            {   // prefetch the next slice (next head, or head 0 of this block's next round)
+                const int nh = head + 1 < a.heads ? head + 1 : 0;
+                if (head + 1 < a.heads || round + (int)gridDim.x < rounds) load_slice(nh);
+            }
+            const __bf16* wfrag = wb + lane * 8;
+
+            // ---- projections ----------------------------------------------------------------------
+            f32x16 q, k, v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[r] = k[r] = v[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 wq = *reinterpret_cast<const bf16x8*>(wfrag + (0 * KS + ks) * 512);
+                const bf16x8 wk = *reinterpret_cast<const bf16x8*>(wfrag + (1 * KS + ks) * 512);
+                const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wfrag + (2 * KS + ks) * 512);
+                q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq, xh[ks], q, 0, 0, 0);
+                k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk, xh[ks], k, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[ks], wv, v, 0, 0, 0);
+            }
+            // q scale + half-split rotary (feature d pairs with d+16 = register r with r+8)
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rg + e;
+                    const float q1 = q[r] * a.q_scale, q2 = q[r + 8] * a.q_scale;
+                    q[r] = q1 * rc[rg][e] - q2 * rs[rg][e];
+                    q[r + 8] = q2 * rc[rg][e] + q1 * rs[rg][e];
+                    const float k1 = k[r], k2 = k[r + 8];
+                    k[r] = k1 * rc[rg][e] - k2 * rs[rg][e];
+                    k[r + 8] = k2 * rc[rg][e] + k1 * rs[rg][e];
+                }
+            // ---- S^T = K Q^T, softmax over keys (this lane's 16 registers + the other half) --------
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 0), acc_frag(q, 0), st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 1), acc_frag(q, 1), st, 0, 0, 0);
+            const float* bl = biasl + (head * F + q_f) * F;
+            float mx = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sv = (kmask >> r) & 1u ? st[r] + bl[kf[r]] : -1e30f;
+                st[r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = (kmask >> r) & 1u ? __expf(st[r] - mx) : 0.f;
+                st[r] = p;
+                lsum += p;
+            }
+            lsum += __shfl_xor(lsum, 32);
+            // ---- O^T = V^T P^T ---------------------------------------------------------------------
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(v, 0), acc_frag(st, 0), o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(v, 1), acc_frag(st, 1), o, 0, 0, 0);
+            const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= inv;
+            // ---- output projection, accumulated over heads ------------------------------------------
+            const bf16x8 o0 = acc_frag(o, 0), o1 = acc_frag(o, 1);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wfrag + (3 * KS + 2 * ct) * 512);
+                const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wfrag + (3 * KS + 2 * ct + 1) * 512);
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, o0, oacc[ct], 0, 0, 0);
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, o1, oacc[ct], 0, 0, 0);
+            }
+        }
+
+        // ---- residual + store: registers (4u+v) of tile ct hold channel 32ct + 16(u>>1) + 8 half + 4(u&1) + v
+        if (rowvalid) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int kl = 0; kl < 2; ++kl) {
+                    const long long off = grow * C + (2 * ct + kl) * 16 + 8 * half;
+                    const bf16x8 xr = *reinterpret_cast<const bf16x8*>(a.x + off);
+                    bf16x8 out;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) out[e] = f2bf(oacc[ct][8 * kl + e] + (float)xr[e]);
+                    *reinterpret_cast<bf16x8*>(a.y + off) = out;
+                }
+        }
+    }
+}
+
+}   // namespace
+
+// k-slot -> accumulator-row order of v_mfma_f32_32x32x16_bf16 (k-step s, element j, lane half h)
+static inline int slot_row(int s, int j, int h) { return (j & 3) + 16 * s + 8 * (j >> 2) + 4 * h; }
+
+static inline uint16_t host_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+extern "C" size_t vdmi_pack_tattn_elems(int c, int heads) {
+    return (size_t)heads * (3 * (c / 16) + 2 * (c / 32)) * 512;
+}
+
+// HOST.  wqkv: float [3*heads*32][c] (LayerNorm gamma already folded in), wout: float [c][heads*32].
+extern "C" int vdmi_pack_tattn(const float* wqkv, const float* wout, int c, int heads, uint16_t* out) {
+    if (!wqkv || !wout || !out) return VDMI_E_ARG;
+    if (c % 32 || c <= 0 || heads <= 0) return VDMI_E_SHAPE;
+    const int KS = c / 16, CT = c / 32, hid = heads * 32;
+    size_t o = 0;
+    for (int h = 0; h < heads; ++h) {
+        for (int t = 0; t < 3; ++t)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j)
+                        out[o++] = host_bf16(wqkv[(size_t)(t * hid + h * 32 + (lane & 31)) * c + ks * 16 + 8 * (lane >> 5) + j]);
+        for (int ct = 0; ct < CT; ++ct)
+            for (int s = 0; s < 2; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int arow = lane & 31, u = arow >> 3, hh = (arow >> 2) & 1, vv = arow & 3;
+                    const int chan = 32 * ct + 16 * (u >> 1) + 8 * hh + 4 * (u & 1) + vv;
+                    for (int j = 0; j < 8; ++j)
+                        out[o++] = host_bf16(wout[(size_t)chan * hid + h * 32 + slot_row(s, j, lane >> 5)]);
+                }
+    }
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const float* bias, const float* rot_cos,
+                                const float* rot_sin, int b, int f, int hw, int c, int heads, float q_scale,
+                                float eps, vdmi_stream stream) {
+    if (!x || !y || !wpack) return VDMI_E_ARG;
+    if (b <= 0 || f <= 0 || f > 32 || hw <= 0 || heads <= 0 || (rot_cos && !rot_sin)) return VDMI_E_SHAPE;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(wpack)) return VDMI_E_ALIGN;
+    TAttnArgs a;
+    a.x = static_cast<const __bf16*>(x);
+    a.y = static_cast<__bf16*>(y);
+    a.w = static_cast<const __bf16*>(wpack);
+    a.bias = bias;
+    a.rot_cos = rot_cos;
+    a.rot_sin = rot_sin;
+    a.F = f;
+    a.HW = hw;
+    a.heads = heads;
+    a.sites_per_group = 32 / f;
+    a.groups_per_sample = (hw + a.sites_per_group - 1) / a.sites_per_group;
+    a.ngroups = b * a.groups_per_sample;
+    a.q_scale = q_scale;
+    a.eps = eps;
+    const int rounds = (a.ngroups + 7) / 8;
+    const int grid = rounds < 256 ? rounds : 256;
+    const int nfrag = 3 * (c / 16) + 2 * (c / 32);
+    const size_t lds = (size_t)2 * nfrag * 1024 + (size_t)heads * f * f * 4;
+    if (lds > 160 * 1024) return VDMI_E_LDS;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define VDMI_TATTN_CASE(C_)                                                                                   \
+    if (c == C_) {                                                                                            \
+        static bool attr_done = false;                                                                        \
+        if (!attr_done) {                                                                                     \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<C_>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)    \
+                return VDMI_E_LAUNCH;                                                                         \
+            attr_done = true;                                                                                 \
+        }                                                                                                     \
+        hipLaunchKernelGGL(tattn_fused_kernel<C_>, dim3(grid), dim3(512), lds, st, a);                        \
+        VDMI_LAUNCH_CHECK();                                                                                  \
+        return VDMI_OK;                                                                                       \
+    }
+    VDMI_TATTN_CASE(32)
+    VDMI_TATTN_CASE(64)
+    VDMI_TATTN_CASE(128)
+#undef VDMI_TATTN_CASE
+    return VDMI_E_SHAPE;
+}

@@ -180,6 +180,15 @@ class Plan:
         frames, hw = self.B * self.F, h * w
         rows = frames * hw
         hid = at["hid"]
+        if temporal and at.get("fused") is not None and self.F <= 32:
+            y = self._buf(rows, c)
+            wp = at["fused"]
+            meta = {"kernel": "tattn_fused", "flops": 2.0 * rows * c * 4 * hid + 4.0 * rows * self.F * hid,
+                    "bytes": 4.0 * rows * c}
+            self._add(lambda s, x=x, y=y: lib.vdmi_tattn_fused(
+                x.data_ptr(), y.data_ptr(), wp.data_ptr(), _ptr(self.pos_bias), _ptr(self.rot_cos),
+                _ptr(self.rot_sin), self.B, self.F, hw, c, hid // 32, at["scale"], 1e-5, s), meta, name + ".fused")
+            return y
         qkv = self._buf(rows, 3 * hid)
         a = self._base_args(frames, h, w, qkv, 3 * hid, EPI_QKV_ATTN)
         _fill_pass(a.main, x, c, None, 0, h, w, 1, [(0, 0)], at["wqkv"].data)
@@ -426,7 +435,17 @@ class UnetEngine:
         gamma = pre.norm.gamma.detach().float().reshape(-1).cpu()
         wq = att.to_qkv.weight.detach().float().cpu() * gamma[None, :]        # LayerNorm gamma folded in
         hid = att.to_out.weight.shape[1]
+        cdim = wq.shape[1]
+        fused = None
+        if cdim in (32, 64, 128) and att.rotary_emb is not None:
+            lib = _lib.lib()
+            buf = torch.empty(lib.vdmi_pack_tattn_elems(cdim, hid // 32), dtype=torch.int16)
+            wo = att.to_out.weight.detach().float().cpu().contiguous()
+            wqc = wq.contiguous()
+            check(lib.vdmi_pack_tattn(wqc.data_ptr(), wo.data_ptr(), cdim, hid // 32, buf.data_ptr()), "vdmi_pack_tattn")
+            fused = buf.view(torch.bfloat16).to(device)
         return {
+            "fused": fused,
             "wqkv": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_ATTN, device, want_colsum=True),
             "wout": PackedTaps(att.to_out.weight.detach().float().cpu()[:, :, None], hid, 0, EPI_PLAIN, device),
             "hid": hid,
