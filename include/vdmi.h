@@ -157,6 +157,20 @@ int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const float* bia
                      vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused Residual(PreNorm(SpatialLinearAttention)) (vdp.py:454-479, 331-337, 380-408): three
+ * launches (k/v + context per frame, context fold into to_out, q + output) with x read twice and
+ * y written once.  x, y: bf16 [frames*hw][c]; c in {32, 64, 128}; heads <= 8; dim_head 32.
+ * wpack: vdmi_pack_sla output; w_out: float [c][heads*32]; b_out: float [c];
+ * workspace: vdmi_sla_workspace_bytes() bytes of device memory, 256-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+size_t vdmi_pack_sla_elems(int c, int heads);                                             /* HOST */
+int vdmi_pack_sla(const float* wqkv_gamma_folded, int c, int heads, uint16_t* out);        /* HOST */
+size_t vdmi_sla_workspace_bytes(int frames, int hw, int c, int heads);                     /* HOST */
+int vdmi_sla_fused(const void* x, void* y, const void* wpack, const float* w_out, const float* b_out,
+                   void* workspace, int frames, int hw, int c, int heads, float q_scale, float eps,
+                   vdmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * SpatialLinearAttention pass 1 (vdp.py:471-476): per (frame, head) softmax of k over the
  * n = H*W positions, context = k·vᵀ (32x32), folded into the output projection:
  *   W'[frame][c][h*32+d] = sum_e to_out.weight[c][h*32+e] * context[h][d][e]

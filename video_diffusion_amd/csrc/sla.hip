@@ -1,0 +1,405 @@
+// Fused SpatialLinearAttention for gfx950: Residual(PreNorm(SpatialLinearAttention)) of the
+// reference (vdp.py:454-479 with 331-337, 380-408) in two passes over x plus a small fold, with
+// every activation tile living in MFMA registers.
+//
+//  pass 1  per (frame, part): channel LayerNorm -> K, V projections -> softmax of K over the
+//          positions (online max / sum) -> context^T += V^T E.  One wave per head: the head's Wk, Wv
+//          fragments stay in that wave's registers; the LayerNormed x tile is staged once per
+//          32-row chunk in LDS and shared by the 8 waves.  K and V are produced "rows in registers,
+//          channel on the lane", so the per-channel max/sum over positions is in-lane and the
+//          accumulators are directly the operands of the context product (contraction over rows).
+//  fold    per (frame, head): combine the parts, normalise, fold the 32x32 context into to_out:
+//          W'[c][h*32+d] = sum_e Wout[c][h*32+e] * ctx[d][e], written in pass 2's fragment order.
+//  pass 2  per 32-row chunk (one wave): LayerNorm -> Q projection -> softmax over the head's 32
+//          features (in-lane) -> y = W' q + bias + x.  Wq and the frame's W' live in LDS.
+#include "vdmi_common.h"
+#include <cstring>
+
+namespace {
+
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = f2bf(a[8 * s + j]);
+    return f;
+}
+
+struct SlaArgs {
+    const __bf16* x;
+    __bf16* y;
+    const __bf16* wkv;      // [heads][2][KS][64][8]
+    const __bf16* wq;       // [heads][KS][64][8]
+    const float* w_out;     // [C][heads*32]
+    const float* b_out;     // [C]
+    float* part_m;          // [frames][nparts][heads][32]
+    float* part_l;
+    float* part_ctx;        // [frames][nparts][heads][32 e][32 d]
+    __bf16* wf;             // [frames][heads][CT][2][64][8]
+    int frames, hw, heads, nparts, chunks, chunks_per_part;
+    float q_scale, eps;
+};
+
+// ------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, 2) void sla_pass1_kernel(const SlaArgs a) {
+    constexpr int KS = C / 16, PPR = C / 8, XROW = C + 8, PIECES = 32 * PPR;
+    __shared__ __attribute__((aligned(16))) __bf16 xs[2][32 * XROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int frame = blockIdx.x / a.nparts, part = blockIdx.x - frame * a.nparts;
+    const int c0 = part * a.chunks_per_part;
+    const int c1 = min(c0 + a.chunks_per_part, a.chunks);
+    const int head = wave;
+    const bool active = head < a.heads;
+
+    bf16x8 wk[KS], wv[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (active) {
+            wk[ks] = *reinterpret_cast<const bf16x8*>(a.wkv + (((long long)head * 2 + 0) * KS + ks) * 512 + lane * 8);
+            wv[ks] = *reinterpret_cast<const bf16x8*>(a.wkv + (((long long)head * 2 + 1) * KS + ks) * 512 + lane * 8);
+        } else {
+            wk[ks] = wv[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    // loader role: thread tid < PIECES owns 8 channels of one row of the chunk
+    const bool loader = tid < PIECES;
+    const int lrow = tid / PPR, lpiece = tid % PPR;
+    const long long fbase = (long long)frame * a.hw;
+    auto load_piece = [&](int chunk) -> bf16x8 {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int n = chunk * 32 + lrow;
+        if (loader && n < a.hw) v = *reinterpret_cast<const bf16x8*>(a.x + (fbase + n) * C + lpiece * 8);
+        return v;
+    };
+    auto norm_store = [&](bf16x8 v, __bf16* dst) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
+#pragma unroll
+        for (int m = 1; m < PPR; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        const float mean = s1 * (1.0f / C);
+        const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(((float)v[e] - mean) * rstd);
+        if (loader) *reinterpret_cast<bf16x8*>(dst + lrow * XROW + lpiece * 8) = o;
+    };
+
+    f32x16 ctx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    bf16x8 pre = load_piece(c0);
+    for (int c = c0; c < c1; ++c) {
+        __bf16* xb = xs[(c - c0) & 1];
+        norm_store(pre, xb);
+        __syncthreads();
+        if (c + 1 < c1) pre = load_piece(c + 1);
+
+        f32x16 kacc, vacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kacc[r] = vacc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 xa = *reinterpret_cast<const bf16x8*>(xb + l31 * XROW + ks * 16 + 8 * half);
+            kacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wk[ks], kacc, 0, 0, 0);
+            vacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wv[ks], vacc, 0, 0, 0);
+        }
+        // rows (positions) are in the registers, the head's feature d is this lane's column
+        float tmax = -1e30f;
+        unsigned vmask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (c * 32 + acc_row(r, half) < a.hw) { vmask |= 1u << r; tmax = fmaxf(tmax, kacc[r]); }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = (vmask >> r) & 1u ? __expf(kacc[r] - m_new) : 0.f;
+            const __bf16 eb = f2bf(e);
+            kacc[r] = (float)eb;
+            lsum += (float)eb;
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctx[r] *= alpha;
+        // ctx^T[e][d] += sum_n V[n][e] * E[n][d]
+        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vacc, 0), acc_frag(kacc, 0), ctx, 0, 0, 0);
+        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vacc, 1), acc_frag(kacc, 1), ctx, 0, 0, 0);
+    }
+
+    if (active) {
+        const long long pbase = ((long long)frame * a.nparts + part) * a.heads + head;
+        if (half == 0) {
+            a.part_m[pbase * 32 + l31] = m_run;
+            a.part_l[pbase * 32 + l31] = l_run;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.part_ctx[(pbase * 32 + acc_row(r, half)) * 32 + l31] = ctx[r];
+    }
+}
+
+// k-slot -> accumulator-row order of v_mfma_f32_32x32x16_bf16 (k-step s, element j, lane half h)
+__host__ __device__ inline int slot_row(int s, int j, int h) { return (j & 3) + 16 * s + 8 * (j >> 2) + 4 * h; }
+// accumulator row a of channel tile ct -> output channel (8 consecutive channels per register pair)
+__host__ __device__ inline int out_chan(int ct, int arow) {
+    const int u = arow >> 3, hh = (arow >> 2) & 1, vv = arow & 3;
+    return 32 * ct + 16 * (u >> 1) + 8 * hh + 4 * (u & 1) + vv;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sla_fold_kernel(const SlaArgs a, int c) {
+    __shared__ float ctxn[32][33];   // [d][e]
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x / a.heads, head = blockIdx.x - frame * a.heads;
+    const int CT = c / 32, hid = a.heads * 32;
+    // combine the parts of this (frame, head): per feature d
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        const int e = idx >> 5, d = idx & 31;
+        float m = -1e30f;
+        for (int p = 0; p < a.nparts; ++p)
+            m = fmaxf(m, a.part_m[(((long long)frame * a.nparts + p) * a.heads + head) * 32 + d]);
+        float l = 0.f, s = 0.f;
+        for (int p = 0; p < a.nparts; ++p) {
+            const long long pb = ((long long)frame * a.nparts + p) * a.heads + head;
+            const float w = __expf(a.part_m[pb * 32 + d] - m);
+            l += w * a.part_l[pb * 32 + d];
+            s += w * a.part_ctx[(pb * 32 + e) * 32 + d];
+        }
+        ctxn[d][e] = s / l;
+    }
+    __syncthreads();
+    __bf16* wf = a.wf + (((long long)frame * a.heads + head) * CT) * 2 * 512;
+    // element (ct, s, lane, j) = W'[out_chan(ct, lane&31)][head*32 + slot_row(s, j, lane>>5)]
+    for (int idx = tid; idx < CT * 2 * 512; idx += 256) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) & 1, ct = idx >> 10;
+        const int co = out_chan(ct, lane & 31), d = slot_row(s, j, lane >> 5);
+        const float* wr = a.w_out + (long long)co * hid + head * 32;
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) acc += wr[e] * ctxn[d][e];
+        wf[idx] = f2bf(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, 2) void sla_pass2_kernel(const SlaArgs a) {
+    constexpr int KS = C / 16, CT = C / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* wq = reinterpret_cast<__bf16*>(smem);                 // [heads][KS][512]
+    __bf16* wf = wq + a.heads * KS * 512;                         // [heads][CT][2][512]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int frame = blockIdx.x / a.nparts, part = blockIdx.x - frame * a.nparts;
+    const int c0 = part * a.chunks_per_part;
+    const int c1 = min(c0 + a.chunks_per_part, a.chunks);
+
+    {
+        const int nq = a.heads * KS * 512 / 8, nf = a.heads * CT * 2 * 512 / 8;
+        const __bf16* wfg = a.wf + (long long)frame * a.heads * CT * 2 * 512;
+        for (int i = tid; i < nq; i += 512)
+            *reinterpret_cast<bf16x8*>(wq + i * 8) = *reinterpret_cast<const bf16x8*>(a.wq + i * 8);
+        for (int i = tid; i < nf; i += 512)
+            *reinterpret_cast<bf16x8*>(wf + i * 8) = *reinterpret_cast<const bf16x8*>(wfg + i * 8);
+    }
+    __syncthreads();
+
+    for (int c = c0 + wave; c < c1; c += 8) {
+        const int n = c * 32 + l31;
+        const bool rowvalid = n < a.hw;
+        const long long grow = (long long)frame * a.hw + n;
+        bf16x8 xh[KS];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (rowvalid) v = *reinterpret_cast<const bf16x8*>(a.x + grow * C + ks * 16 + 8 * half);
+            xh[ks] = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
+        }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const float mean = s1 * (1.0f / C);
+        const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xh[ks][e] = f2bf(((float)xh[ks][e] - mean) * rstd);
+
+        f32x16 oacc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[ct][r] = 0.f;
+
+        for (int head = 0; head < a.heads; ++head) {
+            f32x16 q;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(wq + (head * KS + ks) * 512 + lane * 8);
+                q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xh[ks], q, 0, 0, 0);
+            }
+            // softmax over the head's 32 features: 16 registers here + 16 in lane ^ 32
+            float mx = q[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, q[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { q[r] = __expf(q[r] - mx); sum += q[r]; }
+            sum += __shfl_xor(sum, 32);
+            const float inv = a.q_scale / sum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[r] *= inv;
+            const bf16x8 q0 = acc_frag(q, 0), q1 = acc_frag(q, 1);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wf + ((head * CT + ct) * 2 + 0) * 512 + lane * 8);
+                const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wf + ((head * CT + ct) * 2 + 1) * 512 + lane * 8);
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, q0, oacc[ct], 0, 0, 0);
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, q1, oacc[ct], 0, 0, 0);
+            }
+        }
+        if (rowvalid) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int kl = 0; kl < 2; ++kl) {
+                    const int ch = (2 * ct + kl) * 16 + 8 * half;
+                    const long long off = grow * C + ch;
+                    const bf16x8 xr = *reinterpret_cast<const bf16x8*>(a.x + off);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b_out + ch);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b_out + ch + 4);
+                    bf16x8 out;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        out[e] = f2bf(oacc[ct][8 * kl + e] + (e < 4 ? b0[e] : b1[e - 4]) + (float)xr[e]);
+                    *reinterpret_cast<bf16x8*>(a.y + off) = out;
+                }
+        }
+    }
+}
+
+inline uint16_t host_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// The split of a frame's positions into parts depends on hw only (never on the batch), so a
+// sample's result is bit-identical however the batch is sharded.
+void sla_geometry(int frames, int hw, int* nparts, int* chunks, int* cpp) {
+    (void)frames;
+    *chunks = (hw + 31) / 32;
+    int np = *chunks / 16;
+    if (np > 8) np = 8;
+    if (np < 1) np = 1;
+    *cpp = (*chunks + np - 1) / np;
+    *nparts = (*chunks + *cpp - 1) / *cpp;
+}
+
+}   // namespace
+
+extern "C" size_t vdmi_pack_sla_elems(int c, int heads) { return (size_t)heads * 3 * (c / 16) * 512; }
+
+// HOST.  wqkv: float [3*heads*32][c] (LayerNorm gamma folded in).  out: k,v fragments
+// [heads][2][c/16][64][8] followed by q fragments [heads][c/16][64][8].
+extern "C" int vdmi_pack_sla(const float* wqkv, int c, int heads, uint16_t* out) {
+    if (!wqkv || !out) return VDMI_E_ARG;
+    if (c <= 0 || c % 32 || heads <= 0) return VDMI_E_SHAPE;
+    const int KS = c / 16, hid = heads * 32;
+    size_t o = 0;
+    for (int h = 0; h < heads; ++h)
+        for (int t = 1; t <= 2; ++t)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j)
+                        out[o++] = host_bf16(wqkv[(size_t)(t * hid + h * 32 + (lane & 31)) * c + ks * 16 + 8 * (lane >> 5) + j]);
+    for (int h = 0; h < heads; ++h)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j)
+                    out[o++] = host_bf16(wqkv[(size_t)(h * 32 + (lane & 31)) * c + ks * 16 + 8 * (lane >> 5) + j]);
+    return VDMI_OK;
+}
+
+extern "C" size_t vdmi_sla_workspace_bytes(int frames, int hw, int c, int heads) {
+    int nparts, chunks, cpp;
+    sla_geometry(frames, hw, &nparts, &chunks, &cpp);
+    const size_t parts = (size_t)frames * nparts * heads;
+    size_t bytes = parts * 32 * 4 * 2 + parts * 32 * 32 * 4;
+    bytes = (bytes + 255) / 256 * 256;
+    bytes += (size_t)frames * heads * (c / 32) * 2 * 512 * 2;
+    return bytes;
+}
+
+extern "C" int vdmi_sla_fused(const void* x, void* y, const void* wpack, const float* w_out, const float* b_out,
+                              void* workspace, int frames, int hw, int c, int heads, float q_scale, float eps,
+                              vdmi_stream stream) {
+    if (!x || !y || !wpack || !w_out || !b_out || !workspace) return VDMI_E_ARG;
+    if (frames <= 0 || hw <= 0 || heads <= 0 || heads > 8 || (c != 32 && c != 64 && c != 128)) return VDMI_E_SHAPE;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(wpack) || !aligned16(workspace) || !aligned16(b_out))
+        return VDMI_E_ALIGN;
+    SlaArgs a;
+    a.x = static_cast<const __bf16*>(x);
+    a.y = static_cast<__bf16*>(y);
+    a.wkv = static_cast<const __bf16*>(wpack);
+    a.wq = a.wkv + (size_t)heads * 2 * (c / 16) * 512;
+    a.w_out = w_out;
+    a.b_out = b_out;
+    a.frames = frames;
+    a.hw = hw;
+    a.heads = heads;
+    sla_geometry(frames, hw, &a.nparts, &a.chunks, &a.chunks_per_part);
+    const size_t parts = (size_t)frames * a.nparts * heads;
+    char* ws = static_cast<char*>(workspace);
+    a.part_m = reinterpret_cast<float*>(ws);
+    a.part_l = a.part_m + parts * 32;
+    a.part_ctx = a.part_l + parts * 32;
+    size_t off = parts * 32 * 4 * 2 + parts * 32 * 32 * 4;
+    off = (off + 255) / 256 * 256;
+    a.wf = reinterpret_cast<__bf16*>(ws + off);
+    a.q_scale = q_scale;
+    a.eps = eps;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)(frames * a.nparts));
+    const size_t lds2 = ((size_t)heads * (c / 16) + (size_t)heads * (c / 32) * 2) * 1024;
+    if (lds2 > 160 * 1024) return VDMI_E_LDS;
+#define VDMI_SLA_CASE(C_)                                                                                     \
+    if (c == C_) {                                                                                            \
+        static bool attr_done = false;                                                                        \
+        if (!attr_done) {                                                                                     \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(sla_pass2_kernel<C_>),                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)    \
+                return VDMI_E_LAUNCH;                                                                         \
+            attr_done = true;                                                                                 \
+        }                                                                                                     \
+        hipLaunchKernelGGL(sla_pass1_kernel<C_>, grid, dim3(512), 0, st, a);                                  \
+        VDMI_LAUNCH_CHECK();                                                                                  \
+        hipLaunchKernelGGL(sla_fold_kernel, dim3((unsigned)(frames * heads)), dim3(256), 0, st, a, c);        \
+        VDMI_LAUNCH_CHECK();                                                                                  \
+        hipLaunchKernelGGL(sla_pass2_kernel<C_>, grid, dim3(512), lds2, st, a);                               \
+        VDMI_LAUNCH_CHECK();                                                                                  \
+        return VDMI_OK;                                                                                       \
+    }
+    VDMI_SLA_CASE(32)
+    VDMI_SLA_CASE(64)
+    VDMI_SLA_CASE(128)
+#undef VDMI_SLA_CASE
+    return VDMI_E_SHAPE;
+}

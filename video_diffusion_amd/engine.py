@@ -220,6 +220,17 @@ class Plan:
         rows = frames * hw
         hid = sl["hid"]
         heads = hid // 32
+        if sl.get("fused") is not None:
+            y = self._buf(rows, c)
+            ws = torch.empty(lib.vdmi_sla_workspace_bytes(frames, hw, c, heads), device=self.device, dtype=torch.uint8)
+            self.keep.append(ws)
+            wp, wout, bout = sl["fused"], sl["wout_f32"], sl["bout"]
+            meta = {"kernel": "sla_fused", "flops": 2.0 * rows * c * 4 * hid + 4.0 * rows * 32 * hid,
+                    "bytes": 6.0 * rows * c}
+            self._add(lambda s, x=x, y=y, ws=ws: lib.vdmi_sla_fused(
+                x.data_ptr(), y.data_ptr(), wp.data_ptr(), wout.data_ptr(), bout.data_ptr(), ws.data_ptr(),
+                frames, hw, c, heads, sl["scale"], 1e-5, s), meta, name + ".fused")
+            return y
         qs = self._buf(rows, hid)
         kvt = torch.empty(frames, 2 * hid, hw, device=self.device, dtype=torch.bfloat16)
         self.keep.append(kvt)
@@ -458,7 +469,16 @@ class UnetEngine:
         gamma = pre.norm.gamma.detach().float().reshape(-1).cpu()
         wq = sl.to_qkv.weight.detach().float().cpu().reshape(sl.to_qkv.weight.shape[0], -1) * gamma[None, :]
         hid = sl.to_out.weight.shape[1]
+        cdim = wq.shape[1]
+        fused = None
+        if cdim in (32, 64, 128) and hid // 32 <= 8:
+            lib = _lib.lib()
+            buf = torch.empty(lib.vdmi_pack_sla_elems(cdim, hid // 32), dtype=torch.int16)
+            wqc = wq.contiguous()
+            check(lib.vdmi_pack_sla(wqc.data_ptr(), cdim, hid // 32, buf.data_ptr()), "vdmi_pack_sla")
+            fused = buf.view(torch.bfloat16).to(device)
         return {
+            "fused": fused,
             "wqkv": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_SLA, device, want_colsum=True),
             "wout_f32": sl.to_out.weight.detach().float().reshape(sl.to_out.weight.shape[0], -1).to(device).contiguous(),
             "bout": sl.to_out.bias.detach().float().to(device).contiguous(),
