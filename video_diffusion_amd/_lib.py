@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvdmi.so")
+LIB_PATH = os.environ.get("VDMI_LIB_PATH") or os.path.join(_HERE, "libvdmi.so")
 
 MAX_TAPS = 16
 EPI_PLAIN, EPI_NORM_SILU, EPI_QKV_ATTN, EPI_QKV_SLA = 0, 1, 2, 3

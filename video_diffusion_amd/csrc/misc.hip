@@ -119,6 +119,9 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
     float* h1 = e0 + dim;                         // [8*dim]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
+    // gridDim.y workgroups share one batch element: each recomputes the (small) first layer and
+    // produces a slice of the second layer's rows
+    const int nsplit = gridDim.y, split = blockIdx.y;
     const int td = 8 * dim, half = dim / 2, ed = td + cond_dim;
     const float tv = (float)t[b];
     const float step = logf(10000.0f) / (float)(half - 1);
@@ -138,7 +141,9 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
         }
     }
     __syncthreads();
-    for (int j = wave; j < td; j += 4) {
+    const int rows_per = (td + nsplit - 1) / nsplit;
+    const int j0 = split * rows_per, j1 = min(td, j0 + rows_per);
+    for (int j = j0 + wave; j < j1; j += 4) {
         float s = 0.f;
         for (int k = lane; k < td; k += 64) s += w2[(size_t)j * td + k] * h1[k];
         s = wave_sum(s);
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
             emb_silu[(size_t)b * ed + j] = silu_f(v);
         }
     }
-    for (int k = tid; k < cond_dim; k += 256) {
+    for (int k = tid; split == 0 && k < cond_dim; k += 256) {
         const bool nul = null_mask && null_mask[b];
         const float v = nul ? null_cond[k] : cond[(size_t)b * cond_dim + k];
         emb_raw[(size_t)b * ed + td + k] = v;
@@ -330,7 +335,7 @@ extern "C" int vdmi_time_embed(const int64_t* t, int b, int dim, const float* w1
     if (cond_dim > 0 && (!cond || (null_mask && !null_cond))) return VDMI_E_ARG;
     const size_t lds = (size_t)9 * dim * 4;
     if (lds > 64 * 1024) return VDMI_E_LDS;
-    hipLaunchKernelGGL(time_embed_kernel, dim3((unsigned)b), dim3(256), lds, static_cast<hipStream_t>(stream), t, dim,
+    hipLaunchKernelGGL(time_embed_kernel, dim3((unsigned)b, 16u), dim3(256), lds, static_cast<hipStream_t>(stream), t, dim,
                        w1, b1, w2, b2, cond, null_cond, null_mask, cond_dim, emb_silu, emb_raw);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;

@@ -17,6 +17,29 @@
 #include "vdmi_common.h"
 #include <cstring>
 
+// Diagnostic builds only (-DVDMI_DIAG_STAMPS, never shipped): thread 0 of every workgroup records
+// s_memtime at a few points into a buffer whose address comes from the VDMI_DIAG_PTR environment
+// variable; nothing else reads that buffer.
+#ifdef VDMI_DIAG_STAMPS
+#include <cstdlib>
+#define VDMI_STAMP(ptr, slot)                                                                         \
+    do {                                                                                              \
+        if ((ptr) && threadIdx.x == 0)                                                                \
+            (ptr)[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = \
+                __builtin_readcyclecounter();                                                         \
+    } while (0)
+#define VDMI_STAMP_T() __builtin_readcyclecounter()
+#define VDMI_STAMP_ADD(ptr, slot, val)                                                                \
+    do {                                                                                              \
+        if ((ptr) && threadIdx.x == 0)                                                                \
+            (ptr)[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] += (val); \
+    } while (0)
+#else
+#define VDMI_STAMP(ptr, slot) do { } while (0)
+#define VDMI_STAMP_T() 0ull
+#define VDMI_STAMP_ADD(ptr, slot, val) do { } while (0)
+#endif
+
 namespace {
 
 struct PassDev {
@@ -59,12 +82,13 @@ struct KArgs {
     __bf16* out2;
     int sla_hw;
     int heads32;
+    unsigned long long* diag;
 };
 
 template <int BM, int BN, int WM, int WN, int BKC, bool STATS>
 __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32][WM / 32], __bf16* wbuf,
                                          __bf16* patch, float* stats, int frame, int ty, int tx, int ltw,
-                                         int nt, int tid, float ln_eps) {
+                                         int nt, int tid, float ln_eps, unsigned long long* diag = nullptr) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32, KS = BKC / 16, PROW = BKC + 8, PPR = BKC / 8;
     constexpr int WP = BN * BKC / 8 / NT;
@@ -125,23 +149,49 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
                 }
             }
         } else {
-            for (int idx = tid; idx < total; idx += NT) {
-                const int r = idx / PPR, piece = idx % PPR;
-                const int ry = r / g.pw, rx = r - ry * g.pw;
-                const int iy = iy0 + ry, ix = ix0 + rx, ch = cbase + piece * 8;
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w && ch < cs)
-                    v = *reinterpret_cast<const bf16x8*>(src + ((long long)(frame * g.in_h + iy) * g.in_w + ix) * cs + ch);
-                *reinterpret_cast<bf16x8*>(patch + r * PROW + piece * 8) = v;
+            // patch rows advance by NT / PPR per iteration; (ry, rx) is carried instead of divided out
+            constexpr int RSTEP = NT / PPR;
+            static_assert(NT % PPR == 0, "row step must be whole");
+            const int piece = tid % PPR;
+            int r = tid / PPR;
+            int ry = r / g.pw, rx = r - ry * g.pw;
+            const int ch = cbase + piece * 8;
+            const bool chok = ch < cs;
+            const int nrows = g.ph * g.pw;
+            // LB loads are issued back to back before any is written to LDS, so their latencies overlap
+            constexpr int LB = BM >= 128 ? 6 : 2;
+            while (r < nrows) {
+                bf16x8 v[LB];
+                int rr[LB];
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const int iy = iy0 + ry, ix = ix0 + rx;
+                    rr[u] = r;
+                    v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (r < nrows && chok && iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w)
+                        v[u] = *reinterpret_cast<const bf16x8*>(src + ((long long)(frame * g.in_h + iy) * g.in_w + ix) * cs + ch);
+                    r += RSTEP;
+                    rx += RSTEP;
+                    while (rx >= g.pw) { rx -= g.pw; ++ry; }
+                }
+#pragma unroll
+                for (int u = 0; u < LB; ++u)
+                    if (rr[u] < nrows) *reinterpret_cast<bf16x8*>(patch + rr[u] * PROW + piece * 8) = v[u];
             }
         }
 
         for (int t = 0; t < g.ntaps; ++t) {
             const int s = c * g.ntaps + t;
             __bf16* wb = wbuf + (s & 1) * BN * BKC;
+            [[maybe_unused]] const unsigned long long ts0 = VDMI_STAMP_T();
 #pragma unroll
             for (int k = 0; k < WP; ++k) *reinterpret_cast<bf16x8*>(wb + (tid + k * NT) * 8) = wreg[k];
+            [[maybe_unused]] const unsigned long long ts1 = VDMI_STAMP_T();
             __syncthreads();   // patch and this step's weight tile are visible
+            [[maybe_unused]] const unsigned long long ts2 = VDMI_STAMP_T();
+            VDMI_STAMP_ADD(diag, 5, ts1 - ts0);
+            VDMI_STAMP_ADD(diag, 6, ts2 - ts1);
+            if (s == 0) VDMI_STAMP(diag, 1);
             if (s + 1 < nsteps) load_w(s + 1);
             const int to = g.toff[t] * PROW;
 #pragma unroll
@@ -215,16 +265,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
         }
     }
 
+    // accumulators start at the bias (NORM / PLAIN), so the epilogue has no separate bias pass
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int rg = 0; rg < 4; ++rg) {
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == VDMI_EPI_NORM_SILU || EPI == VDMI_EPI_PLAIN) {
+                const int gc = n0 + (wn * MI + i) * 32 + 8 * rg + 4 * h;
+                if (a.bias && gc < a.n) bv = *reinterpret_cast<const f32x4*>(a.bias + gc);
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * rg + e] = bv[e];
+        }
 
     constexpr bool STATS = (EPI == VDMI_EPI_QKV_ATTN || EPI == VDMI_EPI_QKV_SLA);
-    run_pass<BM, BN, WM, WN, BKC, STATS>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps);
+    VDMI_STAMP(a.diag, 0);
+    run_pass<BM, BN, WM, WN, BKC, STATS>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, a.diag);
+    VDMI_STAMP(a.diag, 2);
     if constexpr (STATS) __syncthreads();   // row statistics written by the loader threads
 
     // output row of each of this lane's pixels (-1: outside the image)
@@ -245,18 +306,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int ch = (wn * MI + i) * 32 + 8 * rg + 4 * h;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(par + ch);
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[i][j][4 * rg + e] + bv[e];
-                        acc[i][j][4 * rg + e] = v;
-                        ss[j] += v * v;
-                    }
-            }
+                for (int r = 0; r < 16; ++r) ss[j] += acc[i][j][r] * acc[i][j][r];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) ss[j] += __shfl_xor(ss[j], 32);
         if constexpr (NWN > 1) {
@@ -288,7 +340,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float y = acc[i][j][4 * rg + e] * rinv[j] * gv[e] + sv[e];
+                        const float y = fmaf(acc[i][j][4 * rg + e] * rinv[j], gv[e], sv[e]);
                         acc[i][j][4 * rg + e] = silu_f(y);
                     }
             }
@@ -311,17 +363,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
             }
         }
     } else if constexpr (EPI == VDMI_EPI_PLAIN) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int ch = (wn * MI + i) * 32 + 8 * rg + 4 * h;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(par + ch);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * rg + e] += bv[e];
-            }
+        // bias already in the accumulators
     } else {
         // folded LayerNorm: y = rstd * (acc - mean * colsum)
         float mean[NJ], rstd[NJ];
@@ -408,6 +450,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
         }
     }
 
+    VDMI_STAMP(a.diag, 3);
     // store (bf16, 4 consecutive channels = 8 bytes per lane per register group)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -438,6 +481,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
             }
         }
     }
+    VDMI_STAMP(a.diag, 4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -654,6 +698,9 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         k.out2 = static_cast<__bf16*>(A.out2);
         k.sla_hw = A.sla_hw > 0 ? A.sla_hw : 1;
         k.heads32 = A.n / 3;
+#ifdef VDMI_DIAG_STAMPS
+        if (const char* dp = std::getenv("VDMI_DIAG_PTR")) k.diag = reinterpret_cast<unsigned long long*>(std::strtoull(dp, nullptr, 0));
+#endif
         if (is_qkv && (A.n % 96)) return VDMI_E_SHAPE;
 
         if (best_tiles > 0x7fffffffLL || frames > 65535) return VDMI_E_SHAPE;
@@ -665,6 +712,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if (c.bm == BM_ && c.bn == BN_ && c.wm == WM_ && c.wn == WN_ && c.bkc == BKC_ && epi == EPI_)  \
         return launch<BM_, BN_, WM_, WN_, BKC_, EPI_>(k, grid, lds, stream);
         VDMI_CASE(256, 64, 64, 64, 64, VDMI_EPI_NORM_SILU)
+        VDMI_CASE(256, 64, 64, 64, 32, VDMI_EPI_NORM_SILU)
         VDMI_CASE(128, 128, 64, 64, 64, VDMI_EPI_NORM_SILU)
         VDMI_CASE(64, 256, 64, 64, 64, VDMI_EPI_NORM_SILU)
         VDMI_CASE(32, 512, 32, 128, 32, VDMI_EPI_NORM_SILU)

@@ -15,7 +15,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
 __device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }   // v_cvt_pk_bf16_f32, RNE
 
-__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+// y * sigmoid(y) with the hardware exp2 / rcp (1 ulp-class approximations; the result is rounded to bf16)
+__device__ __forceinline__ float silu_f(float y) {
+    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
+}
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
