@@ -115,7 +115,8 @@ typedef struct vdmi_tapgemm_args {
     int32_t rot_hw;                /* H*W: position of a row = (row / rot_hw) % rot_frames   */
     void* out2;                    /* QKV_SLA: bf16 [frames][512][sla_hw] (k then v)         */
     int32_t sla_hw;
-    int32_t reserved;
+    int32_t tile_bn;               /* PLAIN only: 0 = automatic, 64 = force 64-channel output tiles
+                                      (more pixels per workgroup, less weight traffic)        */
 } vdmi_tapgemm_args;
 
 /* HOST. Tile the library will use for (epilogue, n): *bn = output-channel tile, *bkc = input

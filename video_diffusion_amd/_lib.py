@@ -48,7 +48,7 @@ class TapGemmArgs(C.Structure):
         ("rot_cos", C.c_void_p), ("rot_sin", C.c_void_p),
         ("rot_frames", C.c_int32), ("rot_hw", C.c_int32),
         ("out2", C.c_void_p),
-        ("sla_hw", C.c_int32), ("reserved", C.c_int32),
+        ("sla_hw", C.c_int32), ("tile_bn", C.c_int32),
     ]
 
 

@@ -85,10 +85,14 @@ struct KArgs {
     unsigned long long* diag;
 };
 
-template <int BM, int BN, int WM, int WN, int BKC, bool STATS>
+// pieces (16 B) of the haloed patch one thread may hold in registers while they are in flight
+template <int BM> struct PatchRegs { static constexpr int LB = BM >= 128 ? 12 : (BM >= 64 ? 12 : 2); };
+
+template <int BM, int BN, int WM, int WN, int BKC, bool STATS, class Pro>
 __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32][WM / 32], __bf16* wbuf,
                                          __bf16* patch, float* stats, int frame, int ty, int tx, int ltw,
-                                         int nt, int tid, float ln_eps, unsigned long long* diag = nullptr) {
+                                         int nt, int tid, float ln_eps, Pro&& after_first_loads,
+                                         unsigned long long* diag = nullptr) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32, KS = BKC / 16, PROW = BKC + 8, PPR = BKC / 8;
     constexpr int WP = BN * BKC / 8 / NT;
@@ -126,58 +130,66 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     const int total = g.ph * g.pw * PPR;
     load_w(0);
 
+    // ---- patch staging, software pipelined: the loads of chunk c+1 are in flight during chunk c's MFMAs
+    constexpr int LB = PatchRegs<BM>::LB;
+    constexpr int RSTEP = NT / PPR;
+    static_assert(NT % PPR == 0, "row step must be whole");
+    const int piece = tid % PPR, r0 = tid / PPR, nrows = g.ph * g.pw;
+    bf16x8 pv[STATS ? 1 : LB];
+    auto patch_prefetch = [&](int c) {
+        if constexpr (!STATS) {
+            const __bf16* src;
+            int cs, cbase;
+            if (c < g.nch0) { src = g.src0; cs = g.c0; cbase = c * BKC; }
+            else            { src = g.src1; cs = g.c1; cbase = (c - g.nch0) * BKC; }
+            const int ch = cbase + piece * 8;
+            const bool chok = ch < cs;
+            int ry = r0 / g.pw, rx = r0 - ry * g.pw;
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int iy = iy0 + ry, ix = ix0 + rx;
+                pv[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (r0 + u * RSTEP < nrows && chok && iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w)
+                    pv[u] = *reinterpret_cast<const bf16x8*>(src + ((long long)(frame * g.in_h + iy) * g.in_w + ix) * cs + ch);
+                rx += RSTEP;
+                while (rx >= g.pw) { rx -= g.pw; ++ry; }
+            }
+        }
+    };
+    auto patch_commit = [&]() {
+        if constexpr (!STATS) {
+#pragma unroll
+            for (int u = 0; u < LB; ++u)
+                if (r0 + u * RSTEP < nrows) *reinterpret_cast<bf16x8*>(patch + (r0 + u * RSTEP) * PROW + piece * 8) = pv[u];
+        }
+    };
+    patch_prefetch(0);
+    after_first_loads();   // per-channel parameters, accumulator init: overlaps the loads above
+
     for (int c = 0; c < g.nch; ++c) {
         __syncthreads();   // every wave is done with the previous chunk's patch
-        const __bf16* src;
-        int cs, cbase;
-        if (c < g.nch0) { src = g.src0; cs = g.c0; cbase = c * BKC; }
-        else            { src = g.src1; cs = g.c1; cbase = (c - g.nch0) * BKC; }
-
         if constexpr (STATS) {
+            const __bf16* src;
+            int cs, cbase;
+            if (c < g.nch0) { src = g.src0; cs = g.c0; cbase = c * BKC; }
+            else            { src = g.src1; cs = g.c1; cbase = (c - g.nch0) * BKC; }
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
                 const int idx = tid + k * NT;
                 if (idx < total) {
-                    const int r = idx / PPR, piece = idx % PPR;
-                    const int ix = ix0 + r, ch = cbase + piece * 8;
+                    const int r = idx / PPR, pc = idx % PPR;
+                    const int ix = ix0 + r, ch = cbase + pc * 8;
                     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                     if (ix < g.in_w && ch < cs)
                         v = *reinterpret_cast<const bf16x8*>(src + ((long long)frame * g.in_h * g.in_w + ix) * cs + ch);
-                    *reinterpret_cast<bf16x8*>(patch + r * PROW + piece * 8) = v;
+                    *reinterpret_cast<bf16x8*>(patch + r * PROW + pc * 8) = v;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1[k] += f; s2[k] += f * f; }
                 }
             }
         } else {
-            // patch rows advance by NT / PPR per iteration; (ry, rx) is carried instead of divided out
-            constexpr int RSTEP = NT / PPR;
-            static_assert(NT % PPR == 0, "row step must be whole");
-            const int piece = tid % PPR;
-            int r = tid / PPR;
-            int ry = r / g.pw, rx = r - ry * g.pw;
-            const int ch = cbase + piece * 8;
-            const bool chok = ch < cs;
-            const int nrows = g.ph * g.pw;
-            // LB loads are issued back to back before any is written to LDS, so their latencies overlap
-            constexpr int LB = BM >= 128 ? 6 : 2;
-            while (r < nrows) {
-                bf16x8 v[LB];
-                int rr[LB];
-#pragma unroll
-                for (int u = 0; u < LB; ++u) {
-                    const int iy = iy0 + ry, ix = ix0 + rx;
-                    rr[u] = r;
-                    v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                    if (r < nrows && chok && iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w)
-                        v[u] = *reinterpret_cast<const bf16x8*>(src + ((long long)(frame * g.in_h + iy) * g.in_w + ix) * cs + ch);
-                    r += RSTEP;
-                    rx += RSTEP;
-                    while (rx >= g.pw) { rx -= g.pw; ++ry; }
-                }
-#pragma unroll
-                for (int u = 0; u < LB; ++u)
-                    if (rr[u] < nrows) *reinterpret_cast<bf16x8*>(patch + rr[u] * PROW + piece * 8) = v[u];
-            }
+            patch_commit();
+            if (c + 1 < g.nch) patch_prefetch(c + 1);
         }
 
         for (int t = 0; t < g.ntaps; ++t) {
@@ -187,27 +199,47 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
 #pragma unroll
             for (int k = 0; k < WP; ++k) *reinterpret_cast<bf16x8*>(wb + (tid + k * NT) * 8) = wreg[k];
             [[maybe_unused]] const unsigned long long ts1 = VDMI_STAMP_T();
+#if !defined(VDMI_ABL) || VDMI_ABL != 4
             __syncthreads();   // patch and this step's weight tile are visible
+#else
+            if (s == 0) __syncthreads();
+#endif
             [[maybe_unused]] const unsigned long long ts2 = VDMI_STAMP_T();
             VDMI_STAMP_ADD(diag, 5, ts1 - ts0);
             VDMI_STAMP_ADD(diag, 6, ts2 - ts1);
             if (s == 0) VDMI_STAMP(diag, 1);
+#if !defined(VDMI_ABL) || VDMI_ABL != 3
             if (s + 1 < nsteps) load_w(s + 1);
+#endif
             const int to = g.toff[t] * PROW;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 af[MI], bfr[NJ];
+#if !defined(VDMI_ABL) || VDMI_ABL != 2
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
                     af[i] = *reinterpret_cast<const bf16x8*>(wb + (((wn * MI + i) * KS + ks) * 64 + lane) * 8);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     bfr[j] = *reinterpret_cast<const bf16x8*>(patch + rowoff[j] + to + ks * 16);
+#else
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = wreg[0];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bfr[j] = wreg[0];
+#endif
+#if !defined(VDMI_ABL) || VDMI_ABL != 1
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+                for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bfr[j]));
+#endif
             }
         }
     }
@@ -249,42 +281,47 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
     const int nt = blockIdx.y, frame = blockIdx.z, n0 = nt * BN;
     const int TW = 1 << a.ltw, TH = BM >> a.ltw;
 
-    // per-channel epilogue parameters -> LDS (visible after the barriers of the main loop)
-    for (int c = tid; c < BN; c += NT) {
-        const int gc = n0 + c;
-        const bool ok = gc < a.n;
-        if constexpr (EPI == VDMI_EPI_NORM_SILU) {
-            const int b = frame / a.frames_per_batch;
-            par[c] = (ok && a.bias) ? a.bias[gc] : 0.f;
-            par[BN + c] = ok ? a.gain[b * a.gain_bstride + gc] : 0.f;
-            par[2 * BN + c] = (ok && a.shift) ? a.shift[b * a.shift_bstride + gc] : 0.f;
-        } else if constexpr (EPI == VDMI_EPI_PLAIN) {
-            par[c] = (ok && a.bias) ? a.bias[gc] : 0.f;
-        } else {
-            par[c] = ok ? a.colsum[gc] : 0.f;
-        }
-    }
-
-    // accumulators start at the bias (NORM / PLAIN), so the epilogue has no separate bias pass
     f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == VDMI_EPI_NORM_SILU || EPI == VDMI_EPI_PLAIN) {
-                const int gc = n0 + (wn * MI + i) * 32 + 8 * rg + 4 * h;
-                if (a.bias && gc < a.n) bv = *reinterpret_cast<const f32x4*>(a.bias + gc);
+    // per-channel epilogue parameters -> LDS (visible after the barriers of the main loop) and
+    // accumulator init; run_pass calls this right after issuing its first loads
+    auto prologue = [&]() {
+        for (int c = tid; c < BN; c += NT) {
+            const int gc = n0 + c;
+            const bool ok = gc < a.n;
+            if constexpr (EPI == VDMI_EPI_NORM_SILU) {
+                const int b = frame / a.frames_per_batch;
+                par[c] = (ok && a.bias) ? a.bias[gc] : 0.f;
+                par[BN + c] = ok ? a.gain[b * a.gain_bstride + gc] : 0.f;
+                par[2 * BN + c] = (ok && a.shift) ? a.shift[b * a.shift_bstride + gc] : 0.f;
+            } else if constexpr (EPI == VDMI_EPI_PLAIN) {
+                par[c] = (ok && a.bias) ? a.bias[gc] : 0.f;
+            } else {
+                par[c] = ok ? a.colsum[gc] : 0.f;
             }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][4 * rg + e] = bv[e];
         }
+
+        // accumulators start at the bias (NORM / PLAIN), so the epilogue has no separate bias pass
+    #pragma unroll
+        for (int i = 0; i < MI; ++i)
+    #pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (EPI == VDMI_EPI_NORM_SILU || EPI == VDMI_EPI_PLAIN) {
+                    const int gc = n0 + (wn * MI + i) * 32 + 8 * rg + 4 * h;
+                    if (a.bias && gc < a.n) bv = *reinterpret_cast<const f32x4*>(a.bias + gc);
+                }
+    #pragma unroll
+                for (int j = 0; j < NJ; ++j)
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * rg + e] = bv[e];
+            }
+
+
+    };
 
     constexpr bool STATS = (EPI == VDMI_EPI_QKV_ATTN || EPI == VDMI_EPI_QKV_SLA);
     VDMI_STAMP(a.diag, 0);
-    run_pass<BM, BN, WM, WN, BKC, STATS>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, a.diag);
+    run_pass<BM, BN, WM, WN, BKC, STATS>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag);
     VDMI_STAMP(a.diag, 2);
     if constexpr (STATS) __syncthreads();   // row statistics written by the loader threads
 
@@ -345,7 +382,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
                     }
             }
         if (a.has_res == 1) {
-            run_pass<BM, BN, WM, WN, BKC, false>(a.res, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, 0.f);
+            run_pass<BM, BN, WM, WN, BKC, false>(a.res, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, 0.f, [] {});
             if (a.res_bias) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -451,35 +488,66 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
     }
 
     VDMI_STAMP(a.diag, 3);
-    // store (bf16, 4 consecutive channels = 8 bytes per lane per register group)
+    // ---- store through LDS: each wave transposes its WM x WN tile so that 8 lanes write one pixel's
+    // 128 contiguous bytes (16 B per lane, whole cache lines) instead of 32 lines x 16 B per instruction.
+    constexpr int SROW = WN + 8;                 // staging row (elements), padded against bank conflicts
+    constexpr int CPR = WN / 8;                  // 16-byte chunks per staged row
+    constexpr int RPI = 64 / CPR;                // rows covered by one wave instruction
+    static_assert(64 % CPR == 0 && WM % RPI == 0, "staging geometry");
+    __syncthreads();                             // every wave is done with the patch / weight tiles
+    __bf16* stg = reinterpret_cast<__bf16*>(smem) + wave * WM * SROW;
+    const int srow0 = lane / CPR, schunk = lane % CPR;
+    const int gcw = n0 + wn * WN + schunk * 8;   // first of this lane's 8 channels in the coalesced phases
+    auto staged_orow = [&](int row) -> long long {
+        const int p = wm * WM + row;
+        const int gy = ty * TH + (p >> a.ltw), gx = tx * TW + (p & (TW - 1));
+        return (gy < a.grid_h && gx < a.grid_w)
+                   ? ((long long)frame * a.out_h + gy * a.out_mul + a.out_off_y) * a.out_w + gx * a.out_mul + a.out_off_x
+                   : -1;
+    };
+    bool add_res = false;
+    if constexpr (EPI == VDMI_EPI_PLAIN || EPI == VDMI_EPI_NORM_SILU) {
+        add_res = a.has_res == 2;
+        if (add_res) {
+            // identity residual: fetched with the same coalesced pattern, then added in fp32 below
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        if constexpr (EPI == VDMI_EPI_QKV_SLA) {
-            if ((n0 + (wn * MI + i) * 32) / a.heads32 != 0) continue;
+            for (int k = 0; k < WM / RPI; ++k) {
+                const int row = k * RPI + srow0;
+                const long long orw = staged_orow(row);
+                bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (orw >= 0 && gcw < a.n) rv = *reinterpret_cast<const bf16x8*>(a.res_identity + orw * a.ld_res + gcw);
+                *reinterpret_cast<bf16x8*>(stg + row * SROW + schunk * 8) = rv;
+            }
         }
+    }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (orow[j] < 0) continue;
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int gc = n0 + (wn * MI + i) * 32 + 8 * rg + 4 * h;
-                if (gc >= a.n) continue;
+                __bf16* sp = stg + (j * 32 + (lane & 31)) * SROW + i * 32 + 8 * rg + 4 * h;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e];
-                if constexpr (EPI == VDMI_EPI_PLAIN || EPI == VDMI_EPI_NORM_SILU) {
-                    if (a.has_res == 2) {
-                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res_identity + orow[j] * a.ld_res + gc);
+                if (add_res) {
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(sp);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
                 }
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-                *reinterpret_cast<bf16x4*>(a.out + orow[j] * a.ldo + gc) = o;
+                *reinterpret_cast<bf16x4*>(sp) = o;
             }
-        }
+    bool chan_ok = gcw < a.n;
+    if constexpr (EPI == VDMI_EPI_QKV_SLA) chan_ok = chan_ok && (gcw / a.heads32 == 0);   // k, v went to out2
+#pragma unroll
+    for (int k = 0; k < WM / RPI; ++k) {
+        const int row = k * RPI + srow0;
+        const long long orw = staged_orow(row);
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(stg + row * SROW + schunk * 8);
+        if (orw >= 0 && chan_ok) *reinterpret_cast<bf16x8*>(a.out + orw * a.ldo + gcw) = ov;
     }
     VDMI_STAMP(a.diag, 4);
 }
@@ -530,9 +598,11 @@ void finish_pass(const vdmi_tap_pass& p, PassDev* d, int th, int tw) {
 }
 
 size_t lds_bytes(const TileCfg& c, int patch_rows) {
-    const int nwn = c.bn / c.wn;
-    return (size_t)2 * c.bn * c.bkc * 2 + (size_t)3 * c.bn * 4 + (size_t)nwn * c.bm * 4 + (size_t)2 * c.bm * 4 +
-           (size_t)patch_rows * (c.bkc + 8) * 2;
+    const int nwn = c.bn / c.wn, nwaves = (c.bm / c.wm) * nwn;
+    const size_t main_loop = (size_t)2 * c.bn * c.bkc * 2 + (size_t)3 * c.bn * 4 + (size_t)nwn * c.bm * 4 +
+                             (size_t)2 * c.bm * 4 + (size_t)patch_rows * (c.bkc + 8) * 2;
+    const size_t staging = (size_t)nwaves * c.wm * (c.wn + 8) * 2;   // output transpose, reuses the same LDS
+    return main_loop > staging ? main_loop : staging;
 }
 
 constexpr size_t kLdsMax = 160 * 1024;
@@ -553,7 +623,7 @@ int launch(const KArgs& k, dim3 grid, size_t lds, hipStream_t stream) {
     return VDMI_OK;
 }
 
-int pick_tiles(int epi, int n, int stride, TileCfg* cands, int* ncand) {
+int pick_tiles(int epi, int n, int stride, TileCfg* cands, int* ncand, int tile_bn = 0) {
     int k = 0;
     if (epi == VDMI_EPI_NORM_SILU) {
         if (n <= 64) cands[k++] = {256, 64, 64, 64, 64};
@@ -563,7 +633,7 @@ int pick_tiles(int epi, int n, int stride, TileCfg* cands, int* ncand) {
         else if (n <= 1024) cands[k++] = {32, 1024, 32, 128, 32};
         else return VDMI_E_SHAPE;
     } else if (epi == VDMI_EPI_PLAIN) {
-        if (n <= 64) { cands[k++] = {256, 64, 64, 64, 64}; cands[k++] = {64, 64, 32, 32, 64}; }
+        if (n <= 64 || tile_bn == 64) { cands[k++] = {256, 64, 64, 64, 64}; cands[k++] = {64, 64, 32, 32, 64}; }
         else { cands[k++] = {128, 128, 64, 64, 64}; cands[k++] = {64, 128, 32, 64, 64}; }
     } else if (epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA) {
         cands[k++] = {128, 128, 64, 64, 64};
@@ -592,17 +662,17 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     const vdmi_tapgemm_args& A = *args;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int epi = A.epilogue;
-    if (A.n <= 0 || A.n % 32 || A.ldo % 4 || A.frames <= 0 || A.grid_h <= 0 || A.grid_w <= 0) return VDMI_E_SHAPE;
-    if (!aligned16(A.out) || (A.ldo * 2) % 8) return VDMI_E_ALIGN;
+    if (A.n <= 0 || A.n % 32 || A.ldo % 8 || A.frames <= 0 || A.grid_h <= 0 || A.grid_w <= 0) return VDMI_E_SHAPE;
+    if (!aligned16(A.out)) return VDMI_E_ALIGN;
     if (epi == VDMI_EPI_NORM_SILU && !A.gain) return VDMI_E_ARG;
     if ((epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA) && !A.colsum) return VDMI_E_ARG;
     if (epi == VDMI_EPI_QKV_SLA && (!A.out2 || A.sla_hw <= 0)) return VDMI_E_ARG;
-    if (A.has_res == 2 && (!A.res_identity || A.ld_res % 4)) return VDMI_E_ARG;
+    if (A.has_res == 2 && (!A.res_identity || A.ld_res % 8 || !aligned16(A.res_identity))) return VDMI_E_ARG;
     if (A.has_res == 1 && epi != VDMI_EPI_NORM_SILU) return VDMI_E_ARG;
 
     TileCfg cands[4];
     int ncand = 0;
-    int st = pick_tiles(epi, A.n, A.main.stride, cands, &ncand);
+    int st = pick_tiles(epi, A.n, A.main.stride, cands, &ncand, A.tile_bn);
     if (st != VDMI_OK) return st;
 
     const bool is_qkv = (epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA);
@@ -651,6 +721,10 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
             int rows = ph * pw;
             if (A.has_res == 1 && c.bm > rows) rows = c.bm;
             if (lds_bytes(c, rows) > kLdsMax) continue;
+            {   // the loader keeps a whole chunk of the patch in registers: rows it can cover
+                const int nthreads = (c.bm / c.wm) * (c.bn / c.wn) * 64, lb = c.bm >= 64 ? 12 : 2;
+                if (!is_qkv && rows > lb * nthreads / (c.bkc / 8)) continue;
+            }
             const long long tiles = (long long)((grid_h + th - 1) / th) * ((grid_w + tw - 1) / tw);
             if (best_ltw < 0 || tiles < best_tiles || (tiles == best_tiles && rows < best_rows)) {
                 best_ltw = ltw;
