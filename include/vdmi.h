@@ -213,6 +213,16 @@ int vdmi_block_scale_shift(const float* emb_silu, int b, int emb_dim, const floa
 /* HOST. RelativePositionBias bucket ids (vdp.py:286-304), int32 [n][n], entry (i,j) = query i, key j. */
 int vdmi_relpos_buckets(int n, int num_buckets, int max_distance, int32_t* out);
 
+/* RMSNorm over channels, * gain, + shift, SiLU, optional + res: the tail of Block.forward (vdp.py:391-427:
+ * F.normalize(x, dim=1) * gamma * sqrt(C), x * (scale + 1) + shift, SiLU) and ResnetBlock's identity
+ * residual add (vdp.py:452), for layers whose convolution ran with VDMI_EPI_PLAIN over split
+ * output-channel tiles.  x, out, res: bf16 [rows][ld*]; gain = gamma*(scale+1) and shift as in
+ * vdmi_tapgemm_args (float, row's batch element = row / rows_per_batch, bstride 0 = shared vector);
+ * c: 64 * {1,2,3,4,6,8,12,16,24,32}. */
+int vdmi_rmsnorm_silu(const void* x, int ldx, void* out, int ldo, int64_t rows, int c, const float* gain,
+                      int64_t gain_bstride, const float* shift, int64_t shift_bstride, int64_t rows_per_batch,
+                      float norm_scale, const void* res, int ld_res, vdmi_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * One DDPM ancestral step (vdp.py:939-952, 985-1002; coefficient gather = extract, vdp.py:835-838):
  *   x0 = srac[t]*x - srmac[t]*eps;  x0 = clamp(x0,-1,1) if clip

@@ -148,6 +148,63 @@ def test_resnet_against_reference_golden(tiny):
     assert rel_err(from_rows(y, B, Fr, H // 2, H // 2), g["downs_1_1"]) < LAYER_TOL
 
 
+@pytest.fixture()
+def tiny_split(monkeypatch):
+    """The tiny model packed with the wide-layer path (split-channel conv + row norm kernel) forced on
+    for its 64-channel blocks; 6x6 images also exercise frame-stacked tiles."""
+    from video_diffusion_amd import engine
+    monkeypatch.setattr(engine, "SPLIT_MIN_CHANNELS", 64)
+    m = make_unet(**TINY)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = golden("tiny_ops")
+    B, _, Fr, H, _ = [int(v) for v in g["shape"]]
+    L = Layers(m, B, Fr, H, H, g["t"])
+    assert L.eng.packed["downs"][1]["rb0"]["w1"].tile_bn == 64
+    return dict(m=m, sd=sd, cfg=oracle_cfg(**TINY), g=g, L=L, B=B, F=Fr, H=H)
+
+
+@pytest.mark.parametrize("name,pkey,key,split", [
+    ("downs.1.0", lambda P: P["downs"][1]["rb0"], "a32h", (32,)),        # res_conv
+    ("downs.1.1", lambda P: P["downs"][1]["rb1"], "a64h", (64,)),        # identity residual
+    ("ups.0.0", lambda P: P["ups"][0]["rb0"], "a128h", (64, 64)),        # concat input + res_conv
+])
+def test_resnet_split_path(tiny_split, name, pkey, key, split):
+    B, Fr, H = tiny_split["B"], tiny_split["F"], tiny_split["H"]
+    x = inp("tiny." + key, (B, sum(split), Fr, H // 2, H // 2))
+    assert _resnet_case(tiny_split, name, pkey, x, split, H // 2) < LAYER_TOL
+
+
+@pytest.mark.parametrize("c,rows,with_res,with_shift", [(64, 1000, True, True), (256, 777, False, True),
+                                                        (512, 130, True, False), (1024, 65, False, False),
+                                                        (192, 300, True, True)])
+def test_rmsnorm_silu_rows(c, rows, with_res, with_shift):
+    """vdmi_rmsnorm_silu against torch: F.normalize(x, dim=1) * gain * sqrt(C) + shift, SiLU, + res."""
+    from video_diffusion_amd import _lib
+    rpb = 100
+    nb = (rows + rpb - 1) // rpb
+    x = inp(f"rms.x{c}", (rows, c), scale=2.0).to(torch.bfloat16)
+    res = inp(f"rms.r{c}", (rows, c)).to(torch.bfloat16) if with_res else None
+    gain = (1.0 + 0.5 * inp(f"rms.g{c}", (nb, c))).contiguous()
+    shift = inp(f"rms.s{c}", (nb, c)).contiguous() if with_shift else None
+    xd, gd = x.to(dev()), gain.to(dev())
+    rd = res.to(dev()) if with_res else None
+    sd_ = shift.to(dev()) if with_shift else None
+    out = torch.empty_like(xd)
+    _lib.check(_lib.lib().vdmi_rmsnorm_silu(
+        xd.data_ptr(), c, out.data_ptr(), c, rows, c, gd.data_ptr(), c, sd_.data_ptr() if with_shift else None,
+        c if with_shift else 0, rpb, float(c) ** 0.5, rd.data_ptr() if with_res else None, c if with_res else 0,
+        torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    b = torch.arange(rows) // rpb
+    y = torch.nn.functional.normalize(x.float(), dim=1) * gain[b] * c ** 0.5
+    if with_shift:
+        y = y + shift[b]
+    y = torch.nn.functional.silu(y)
+    if with_res:
+        y = y + res.float()
+    assert rel_err(out.float().cpu(), y) < 4e-3      # fp32 math, one bf16 rounding
+
+
 @pytest.mark.parametrize("name,key,c,div", [("init_temporal_attn", "a32", 32, 1), ("downs.0.3", "a32", 32, 1),
                                             ("mid_temporal_attn", "a64h", 64, 2)])
 def test_temporal_attention(tiny, name, key, c, div):

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--all", action="store_true", help="time every launch of the plan on its own and print a table")
     args = ap.parse_args()
     from video_diffusion_amd import Unet3D
     dev = torch.device("cuda:0")
@@ -31,6 +32,26 @@ def main():
     plan.t_in.fill_(500)
     plan.run()                                  # fills every buffer with realistic data
     torch.cuda.synchronize()
+    if args.all:
+        s = torch.cuda.current_stream().cuda_stream
+        total = 0.0
+        for c in plan.calls:
+            c.fn(s)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                c.fn(s)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            total += ms
+            meta = c.args or {}
+            fl = meta.get("flops", 0.0)
+            print(f"{c.name:34s} {meta.get('kernel', '-'):24s} {ms * 1e3:8.1f} us {fl / ms / 1e9 if fl else 0:7.1f} TFLOP/s "
+                  f"{meta.get('bytes', 0.0) / ms / 1e6:7.0f} GB/s")
+        print(f"sum {total:.3f} ms")
+        return
     calls = [c for c in plan.calls if c.name.startswith(args.layer)]
     assert calls, [c.name for c in plan.calls]
     s = torch.cuda.current_stream().cuda_stream

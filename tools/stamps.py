@@ -34,4 +34,4 @@ print(f"{args.layer}: {len(d)} workgroups, kernel span {(d[:,4].max()-t0).item()
 for i, n in enumerate(names):
     print(f"  {n:40s} mean {ph[:, i].mean():9.0f}  p50 {ph[:, i].median():9.0f}  max {ph[:, i].max():9.0f}")
 print(f"  workgroup lifetime mean {(d[:,4]-d[:,0]).double().mean():.0f}")
-print(f"  inside the tap steps (wave 0): waiting for the weight prefetch + LDS write {d[:,5].double().mean():.0f}, barrier wait {d[:,6].double().mean():.0f}")
+print(f"  inside the tap steps (wave 0): waiting for the weight prefetch + LDS write {d[:,5].double().mean():.0f}, barrier wait {d[:,6].double().mean():.0f}, load issue + ds_read + MFMA section {d[:,7].double().mean():.0f}")

@@ -94,6 +94,9 @@ _SIGNATURES = {
     "vdmi_block_scale_shift": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 +
                                [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdmi_relpos_buckets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vdmi_rmsnorm_silu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                    C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_int,
+                                    C.c_void_p]),
     "vdmi_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs),
                                  C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
 }

@@ -374,3 +374,93 @@ extern "C" int vdmi_ddpm_step(const float* x, const float* eps, const float* z, 
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm over channels + scale/shift + SiLU (+ identity residual) of channels-last rows: the tail of
+// Block.forward (reference vdp.py:391-427) and the ResnetBlock residual add (vdp.py:452) for wide
+// layers whose convolution is split over output-channel tiles.
+// LPR lanes share a row, each holding NV groups of 8 channels; the row's sum of squares is an
+// in-wave butterfly.
+// ------------------------------------------------------------------------------------------
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const __bf16* __restrict__ x, int ldx,
+                                                           __bf16* __restrict__ out, int ldo, long long rows,
+                                                           const float* __restrict__ gain, long long gain_bstride,
+                                                           const float* __restrict__ shift, long long shift_bstride,
+                                                           long long rows_per_batch, float norm_scale,
+                                                           const __bf16* __restrict__ res, int ld_res) {
+    constexpr int RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < rows;
+    const long long r = live ? row : rows - 1;
+    bf16x8 v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k] = *reinterpret_cast<const bf16x8*>(x + r * ldx + (k * LPR + sub) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[k][e]; ss += f * f; }
+    }
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) ss += __shfl_xor(ss, m);
+    const float rinv = norm_scale / fmaxf(sqrtf(ss), 1e-12f);
+    const long long b = r / rows_per_batch;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int ch = (k * LPR + sub) * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gain + b * gain_bstride + ch);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gain + b * gain_bstride + ch + 4);
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        if (shift) {
+            s0 = *reinterpret_cast<const f32x4*>(shift + b * shift_bstride + ch);
+            s1 = *reinterpret_cast<const f32x4*>(shift + b * shift_bstride + ch + 4);
+        }
+        bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (res) rv = *reinterpret_cast<const bf16x8*>(res + r * ld_res + ch);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = e < 4 ? g0[e & 3] : g1[e & 3], sh = e < 4 ? s0[e & 3] : s1[e & 3];
+            o[e] = f2bf(silu_f(fmaf((float)v[k][e] * rinv, g, sh)) + (float)rv[e]);
+        }
+        if (live) *reinterpret_cast<bf16x8*>(out + r * ldo + ch) = o;
+    }
+}
+
+extern "C" int vdmi_rmsnorm_silu(const void* x, int ldx, void* out, int ldo, int64_t rows, int c, const float* gain,
+                                 int64_t gain_bstride, const float* shift, int64_t shift_bstride,
+                                 int64_t rows_per_batch, float norm_scale, const void* res, int ld_res,
+                                 vdmi_stream stream_) {
+    if (!x || !out || !gain || rows <= 0 || rows_per_batch <= 0) return VDMI_E_ARG;
+    if (c < 64 || c % 64 || ldx % 8 || ldo % 8 || (res && ld_res % 8) || gain_bstride % 4 || shift_bstride % 4)
+        return VDMI_E_SHAPE;
+    if (!aligned16(x) || !aligned16(out) || !aligned16(gain) || (shift && !aligned16(shift)) || (res && !aligned16(res)))
+        return VDMI_E_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const __bf16* xp = static_cast<const __bf16*>(x);
+    __bf16* op = static_cast<__bf16*>(out);
+    const __bf16* rp = static_cast<const __bf16*>(res);
+#define VDMI_RMS_CASE(LPR_, NV_)                                                                            \
+    if (c == LPR_ * NV_ * 8) {                                                                              \
+        const long long blocks = (rows + (256 / LPR_) - 1) / (256 / LPR_);                                  \
+        if (blocks > 0x7fffffffLL) return VDMI_E_SHAPE;                                                     \
+        hipLaunchKernelGGL((rmsnorm_silu_kernel<LPR_, NV_>), dim3((unsigned)blocks), dim3(256), 0, stream,  \
+                           xp, ldx, op, ldo, (long long)rows, gain, (long long)gain_bstride, shift,         \
+                           (long long)shift_bstride, (long long)rows_per_batch, norm_scale, rp, ld_res);    \
+        VDMI_LAUNCH_CHECK();                                                                                \
+        return VDMI_OK;                                                                                     \
+    }
+    VDMI_RMS_CASE(8, 1)     // 64
+    VDMI_RMS_CASE(16, 1)    // 128
+    VDMI_RMS_CASE(32, 1)    // 256
+    VDMI_RMS_CASE(64, 1)    // 512
+    VDMI_RMS_CASE(64, 2)    // 1024
+    VDMI_RMS_CASE(64, 4)    // 2048
+    VDMI_RMS_CASE(8, 3)     // 192
+    VDMI_RMS_CASE(16, 3)    // 384
+    VDMI_RMS_CASE(32, 3)    // 768
+    VDMI_RMS_CASE(64, 3)    // 1536
+#undef VDMI_RMS_CASE
+    return VDMI_E_SHAPE;
+}

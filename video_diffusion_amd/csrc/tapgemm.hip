@@ -56,6 +56,9 @@ struct PassDev {
     long long w_group_stride;
     int w_group_frames;
     long long wtile_all;
+    // frame stacking: a tile covers `fstack` whole frames of fs_rows tile rows each (images smaller than
+    // the pixel tile); every frame has its own haloed band of `phf` patch rows.  fstack == 1: off.
+    int fstack, fs_rows, phf, nframes;
 };
 
 struct KArgs {
@@ -86,7 +89,9 @@ struct KArgs {
 };
 
 // pieces (16 B) of the haloed patch one thread may hold in registers while they are in flight
-template <int BM> struct PatchRegs { static constexpr int LB = BM >= 128 ? 12 : (BM >= 64 ? 12 : 2); };
+constexpr int patch_lb(int bm, int nt) {
+    return bm >= 256 ? (13 * 256 + nt - 1) / nt : (bm >= 64 ? (12 * 256 + nt - 1) / nt : 2);
+}
 
 template <int BM, int BN, int WM, int WN, int BKC, bool STATS, class Pro>
 __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32][WM / 32], __bf16* wbuf,
@@ -107,7 +112,12 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     for (int j = 0; j < NJ; ++j) {
         const int p = (wm * NJ + j) * 32 + (lane & 31);
         const int py = p >> ltw, px = p & (TW - 1);
-        rowoff[j] = ((py * g.stride) * g.pw + px * g.stride) * PROW + (lane >> 5) * 8;
+        int prow = py * g.stride;
+        if (g.fstack > 1) {
+            const int fi = min(py / g.fs_rows, g.fstack - 1);
+            prow = fi * g.phf + (py - fi * g.fs_rows) * g.stride;
+        }
+        rowoff[j] = (prow * g.pw + px * g.stride) * PROW + (lane >> 5) * 8;
     }
     const int iy0 = ty * TH * g.stride + g.min_dy, ix0 = tx * TW * g.stride + g.min_dx;
     const __bf16* wg = g.w + (long long)nt * BN * BKC;
@@ -131,11 +141,32 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     load_w(0);
 
     // ---- patch staging, software pipelined: the loads of chunk c+1 are in flight during chunk c's MFMAs
-    constexpr int LB = PatchRegs<BM>::LB;
+    constexpr int LB = patch_lb(BM, NT);
     constexpr int RSTEP = NT / PPR;
     static_assert(NT % PPR == 0, "row step must be whole");
     const int piece = tid % PPR, r0 = tid / PPR, nrows = g.ph * g.pw;
     bf16x8 pv[STATS ? 1 : LB];
+    // source pixel of each patch piece this thread stages (-1: padding) -- the same for every chunk
+    int ppix[STATS ? 1 : LB];
+    if constexpr (!STATS) {
+        int ry = r0 / g.pw, rx = r0 - ry * g.pw;
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            int iy = iy0 + ry, fr = frame;
+            const int ix = ix0 + rx;
+            bool ok = r0 + u * RSTEP < nrows;
+            if (g.fstack > 1) {
+                const int fi = ry / g.phf;
+                iy = g.min_dy + ry - fi * g.phf;
+                fr = frame + fi;
+                ok = ok && fr < g.nframes;
+            }
+            ok = ok && iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w;
+            ppix[u] = ok ? (fr * g.in_h + iy) * g.in_w + ix : -1;
+            rx += RSTEP;
+            while (rx >= g.pw) { rx -= g.pw; ++ry; }
+        }
+    }
     auto patch_prefetch = [&](int c) {
         if constexpr (!STATS) {
             const __bf16* src;
@@ -144,15 +175,11 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
             else            { src = g.src1; cs = g.c1; cbase = (c - g.nch0) * BKC; }
             const int ch = cbase + piece * 8;
             const bool chok = ch < cs;
-            int ry = r0 / g.pw, rx = r0 - ry * g.pw;
 #pragma unroll
             for (int u = 0; u < LB; ++u) {
-                const int iy = iy0 + ry, ix = ix0 + rx;
                 pv[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (r0 + u * RSTEP < nrows && chok && iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w)
-                    pv[u] = *reinterpret_cast<const bf16x8*>(src + ((long long)(frame * g.in_h + iy) * g.in_w + ix) * cs + ch);
-                rx += RSTEP;
-                while (rx >= g.pw) { rx -= g.pw; ++ry; }
+                if (chok && ppix[u] >= 0)
+                    pv[u] = *reinterpret_cast<const bf16x8*>(src + (long long)ppix[u] * cs + ch);
             }
         }
     };
@@ -241,6 +268,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
                 for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bfr[j]));
 #endif
             }
+            VDMI_STAMP_ADD(diag, 7, VDMI_STAMP_T() - ts2);
         }
     }
 
@@ -265,7 +293,8 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
 }
 
 template <int BM, int BN, int WM, int WN, int BKC, int EPI>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(const KArgs a) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
+__attribute__((amdgpu_waves_per_eu((BM >= 256 && BM / WM >= 8) ? 4 : 2))) void tapgemm_kernel(const KArgs a) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -278,8 +307,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave % NWM, wn = wave / NWM;
     const int h = lane >> 5;
     const int tile = blockIdx.x, ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int nt = blockIdx.y, frame = blockIdx.z, n0 = nt * BN;
+    const int nt = blockIdx.y, frame = blockIdx.z * a.main.fstack, n0 = nt * BN;
     const int TW = 1 << a.ltw, TH = BM >> a.ltw;
+    // output row of tile pixel p (-1: outside the image / past the last frame)
+    auto pixel_orow = [&](int p) -> long long {
+        int gy = ty * TH + (p >> a.ltw), fr = frame;
+        const int gx = tx * TW + (p & (TW - 1));
+        if (a.main.fstack > 1) {
+            const int fi = gy / a.main.fs_rows;
+            gy -= fi * a.main.fs_rows;
+            fr += fi;
+            if (fi >= a.main.fstack || fr >= a.main.nframes) return -1;
+        }
+        return (gy < a.grid_h && gx < a.grid_w)
+                   ? ((long long)fr * a.out_h + gy * a.out_mul + a.out_off_y) * a.out_w + gx * a.out_mul + a.out_off_x
+                   : -1;
+    };
 
     f32x16 acc[MI][NJ];
     // per-channel epilogue parameters -> LDS (visible after the barriers of the main loop) and
@@ -329,11 +372,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
     long long orow[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int p = (wm * NJ + j) * 32 + (lane & 31);
-        const int gy = ty * TH + (p >> a.ltw), gx = tx * TW + (p & (TW - 1));
-        orow[j] = (gy < a.grid_h && gx < a.grid_w)
-                      ? ((long long)frame * a.out_h + gy * a.out_mul + a.out_off_y) * a.out_w + gx * a.out_mul + a.out_off_x
-                      : -1;
+        orow[j] = pixel_orow((wm * NJ + j) * 32 + (lane & 31));
     }
 
     if constexpr (EPI == VDMI_EPI_NORM_SILU) {
@@ -498,13 +537,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void tapgemm_kernel(
     __bf16* stg = reinterpret_cast<__bf16*>(smem) + wave * WM * SROW;
     const int srow0 = lane / CPR, schunk = lane % CPR;
     const int gcw = n0 + wn * WN + schunk * 8;   // first of this lane's 8 channels in the coalesced phases
-    auto staged_orow = [&](int row) -> long long {
-        const int p = wm * WM + row;
-        const int gy = ty * TH + (p >> a.ltw), gx = tx * TW + (p & (TW - 1));
-        return (gy < a.grid_h && gx < a.grid_w)
-                   ? ((long long)frame * a.out_h + gy * a.out_mul + a.out_off_y) * a.out_w + gx * a.out_mul + a.out_off_x
-                   : -1;
-    };
+    auto staged_orow = [&](int row) -> long long { return pixel_orow(wm * WM + row); };
     bool add_res = false;
     if constexpr (EPI == VDMI_EPI_PLAIN || EPI == VDMI_EPI_NORM_SILU) {
         add_res = a.has_res == 2;
@@ -607,6 +640,12 @@ size_t lds_bytes(const TileCfg& c, int patch_rows) {
 
 constexpr size_t kLdsMax = 160 * 1024;
 
+// patch rows the loader can hold in registers while a chunk is in flight (patch_lb pieces per thread)
+int patch_row_cap(const TileCfg& c) {
+    const int nthreads = (c.bm / c.wm) * (c.bn / c.wn) * 64;
+    return patch_lb(c.bm, nthreads) * nthreads / (c.bkc / 8);
+}
+
 template <int BM, int BN, int WM, int WN, int BKC, int EPI>
 int launch(const KArgs& k, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_done = false;
@@ -626,14 +665,14 @@ int launch(const KArgs& k, dim3 grid, size_t lds, hipStream_t stream) {
 int pick_tiles(int epi, int n, int stride, TileCfg* cands, int* ncand, int tile_bn = 0) {
     int k = 0;
     if (epi == VDMI_EPI_NORM_SILU) {
-        if (n <= 64) cands[k++] = {256, 64, 64, 64, 64};
+        if (n <= 64) cands[k++] = {256, 64, 32, 64, 64};
         else if (n <= 128) cands[k++] = {128, 128, 64, 64, 64};
         else if (n <= 256) cands[k++] = {64, 256, 64, 64, 64};
         else if (n <= 512) cands[k++] = {32, 512, 32, 128, 32};
         else if (n <= 1024) cands[k++] = {32, 1024, 32, 128, 32};
         else return VDMI_E_SHAPE;
     } else if (epi == VDMI_EPI_PLAIN) {
-        if (n <= 64 || tile_bn == 64) { cands[k++] = {256, 64, 64, 64, 64}; cands[k++] = {64, 64, 32, 32, 64}; }
+        if (n <= 64 || tile_bn == 64) { cands[k++] = {256, 64, 32, 64, 64}; cands[k++] = {64, 64, 32, 32, 64}; }
         else { cands[k++] = {128, 128, 64, 64, 64}; cands[k++] = {64, 128, 32, 64, 64}; }
     } else if (epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA) {
         cands[k++] = {128, 128, 64, 64, 64};
@@ -669,6 +708,8 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if (epi == VDMI_EPI_QKV_SLA && (!A.out2 || A.sla_hw <= 0)) return VDMI_E_ARG;
     if (A.has_res == 2 && (!A.res_identity || A.ld_res % 8 || !aligned16(A.res_identity))) return VDMI_E_ARG;
     if (A.has_res == 1 && epi != VDMI_EPI_NORM_SILU) return VDMI_E_ARG;
+    // the loader indexes source pixels with 32-bit integers
+    if ((long long)A.frames * A.main.in_h * A.main.in_w > 0x7fffffffLL) return VDMI_E_SHAPE;
 
     TileCfg cands[4];
     int ncand = 0;
@@ -722,8 +763,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
             if (A.has_res == 1 && c.bm > rows) rows = c.bm;
             if (lds_bytes(c, rows) > kLdsMax) continue;
             {   // the loader keeps a whole chunk of the patch in registers: rows it can cover
-                const int nthreads = (c.bm / c.wm) * (c.bn / c.wn) * 64, lb = c.bm >= 64 ? 12 : 2;
-                if (!is_qkv && rows > lb * nthreads / (c.bkc / 8)) continue;
+                if (!is_qkv && rows > patch_row_cap(c)) continue;
             }
             const long long tiles = (long long)((grid_h + th - 1) / th) * ((grid_w + tw - 1) / tw);
             if (best_ltw < 0 || tiles < best_tiles || (tiles == best_tiles && rows < best_rows)) {
@@ -732,9 +772,38 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
                 best_rows = rows;
             }
         }
+        // images smaller than the pixel tile: stack whole frames into one tile (shared weights only)
+        int fstack = 1;
+        if (epi == VDMI_EPI_PLAIN && !flat && frames > 1 && mainp.w_group_stride == 0) {
+            long long best_blocks = best_ltw < 0 ? (1LL << 62) : best_tiles * frames;
+            for (int ltw = 0; (1 << ltw) <= c.bm; ++ltw) {
+                const int tw = 1 << ltw, th = c.bm >> ltw;
+                if (tw < grid_w || th < 2 * grid_h) continue;
+                const int fs = th / grid_h < frames ? th / grid_h : frames;
+                const int phf = (grid_h - 1) * mainp.stride + k.main.ph + 1, pw = (tw - 1) * mainp.stride + k.main.pw + 1;
+                const int rows = fs * phf * pw;
+                if (lds_bytes(c, rows) > kLdsMax || rows > patch_row_cap(c)) continue;
+                const long long blocks = (frames + fs - 1) / fs;
+                if (blocks < best_blocks) {
+                    best_blocks = blocks;
+                    best_ltw = ltw;
+                    best_tiles = 1;
+                    best_rows = rows;
+                    fstack = fs;
+                }
+            }
+        }
         if (best_ltw < 0) continue;   // try a smaller pixel tile
         const int tw = 1 << best_ltw, th = c.bm >> best_ltw;
         finish_pass(mainp, &k.main, th, tw);
+        k.main.fstack = fstack;
+        k.main.nframes = frames;
+        if (fstack > 1) {
+            k.main.fs_rows = grid_h;
+            k.main.phf = (grid_h - 1) * mainp.stride + (k.main.ph - ((th - 1) * mainp.stride + 1)) + 1;
+            k.main.ph = fstack * k.main.phf;
+            frames = (frames + fstack - 1) / fstack;   // grid.z: frame groups
+        }
         if (A.has_res == 1) {
             k.res = res_base;
             finish_pass(A.res, &k.res, th, tw);
@@ -786,12 +855,13 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if (c.bm == BM_ && c.bn == BN_ && c.wm == WM_ && c.wn == WN_ && c.bkc == BKC_ && epi == EPI_)  \
         return launch<BM_, BN_, WM_, WN_, BKC_, EPI_>(k, grid, lds, stream);
         VDMI_CASE(256, 64, 64, 64, 64, VDMI_EPI_NORM_SILU)
-        VDMI_CASE(256, 64, 64, 64, 32, VDMI_EPI_NORM_SILU)
+        VDMI_CASE(256, 64, 32, 64, 64, VDMI_EPI_NORM_SILU)
         VDMI_CASE(128, 128, 64, 64, 64, VDMI_EPI_NORM_SILU)
         VDMI_CASE(64, 256, 64, 64, 64, VDMI_EPI_NORM_SILU)
         VDMI_CASE(32, 512, 32, 128, 32, VDMI_EPI_NORM_SILU)
         VDMI_CASE(32, 1024, 32, 128, 32, VDMI_EPI_NORM_SILU)
         VDMI_CASE(256, 64, 64, 64, 64, VDMI_EPI_PLAIN)
+        VDMI_CASE(256, 64, 32, 64, 64, VDMI_EPI_PLAIN)
         VDMI_CASE(64, 64, 32, 32, 64, VDMI_EPI_PLAIN)
         VDMI_CASE(128, 128, 64, 64, 64, VDMI_EPI_PLAIN)
         VDMI_CASE(64, 128, 32, 64, 64, VDMI_EPI_PLAIN)

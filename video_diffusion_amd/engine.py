@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -39,13 +40,16 @@ def tile_for(epilogue: int, n: int) -> Tuple[int, int]:
 class PackedTaps:
     """Weights of one implicit-GEMM pass, packed on the host by vdmi_pack_taps."""
 
-    def __init__(self, w: torch.Tensor, cin0: int, cin1: int, epilogue: int, device, want_colsum=False):
+    def __init__(self, w: torch.Tensor, cin0: int, cin1: int, epilogue: int, device, want_colsum=False,
+                 tile_bn: int = 0):
         # w: float32 [n][cin0+cin1][ntaps] on the CPU
         w = w.detach().to(torch.float32).contiguous().cpu()
         n, cin, ntaps = w.shape
         assert cin == cin0 + cin1
         self.n, self.ntaps, self.cin0, self.cin1 = n, ntaps, cin0, cin1
-        self.bn, self.bkc = tile_for(epilogue, n)
+        self.tile_bn = tile_bn
+        # tile_bn = 64 (PLAIN only): 64-channel output tiles, 64-channel input chunks
+        self.bn, self.bkc = (64, 64) if tile_bn == 64 else tile_for(epilogue, n)
         self.npad = (n + self.bn - 1) // self.bn * self.bn
         lib = _lib.lib()
         elems = lib.vdmi_pack_taps_elems(n, self.npad, cin0, cin1, ntaps, self.bkc)
@@ -56,6 +60,8 @@ class PackedTaps:
         self.data = out.view(torch.bfloat16).to(device)
         self.colsum = colsum.to(device) if want_colsum else None
 
+
+SPLIT_MIN_CHANNELS = int(os.environ.get("VDMI_SPLIT_MIN_CHANNELS", "256"))
 
 TAPS_3x3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 TAPS_4x4_S2 = [(ky - 1, kx - 1) for ky in range(4) for kx in range(4)]
@@ -113,7 +119,7 @@ class Plan:
         # algorithmic work of the launch: 2*M*N*K over the positions computed (main pass + fused 1x1 pass)
         m = a.frames * a.grid_h * a.grid_w
         k = (a.main.c0 + a.main.c1) * a.main.ntaps + ((a.res.c0 + a.res.c1) if a.has_res == 1 else 0)
-        bn, _ = tile_for(a.epilogue, a.n)
+        bn = 64 if a.tile_bn == 64 else tile_for(a.epilogue, a.n)[0]
         in_rows = a.frames * a.main.in_h * a.main.in_w
         meta = {"kernel": f"tapgemm<epi={a.epilogue},bn={bn}>", "flops": 2.0 * m * a.n * k,
                 "bytes": 2.0 * (in_rows * (a.main.c0 + a.main.c1) + m * a.n + a.n * k)}
@@ -134,6 +140,8 @@ class Plan:
         frames = self.B * self.F
         (s0, c0), (s1, c1) = srcs[0], (srcs[1] if len(srcs) > 1 else (None, 0))
         w_pack, bias = pk
+        if w_pack.tile_bn == 64:
+            return self._block_split(name, pk, srcs, h, w, gain, shift, bstride, res)
         out = self._buf(frames * h * w, w_pack.n)
         a = self._base_args(frames, h, w, out, w_pack.n, EPI_NORM_SILU)
         _fill_pass(a.main, s0, c0, s1, c1, h, w, 1, TAPS_3x3, w_pack.data)
@@ -154,6 +162,42 @@ class Plan:
                 a.has_res = 2
                 a.res_identity, a.ld_res = _ptr(rt), rt.shape[1]
         self._tapgemm(a, name)
+        return out
+
+    def _block_split(self, name, pk, srcs, h, w, gain, shift, bstride, res=None) -> torch.Tensor:
+        """Block for wide, small-image layers: the conv runs over split output-channel tiles (more pixels
+        per workgroup, so each weight byte is fetched by far fewer workgroups), RMSNorm + scale/shift +
+        SiLU (+ identity residual) is a separate row kernel, res_conv a plain 1x1 GEMM on top."""
+        lib = _lib.lib()
+        frames = self.B * self.F
+        rows = frames * h * w
+        (s0, c0), (s1, c1) = srcs[0], (srcs[1] if len(srcs) > 1 else (None, 0))
+        w_pack, bias = pk
+        n = w_pack.n
+        raw = self._buf(rows, n)
+        a = self._base_args(frames, h, w, raw, n, EPI_PLAIN)
+        _fill_pass(a.main, s0, c0, s1, c1, h, w, 1, TAPS_3x3, w_pack.data)
+        a.bias = _ptr(bias)
+        a.tile_bn = 64
+        self._tapgemm(a, name + ".conv")
+        identity = res[1] if (res is not None and res[0] == "identity") else None
+        out = self._buf(rows, n)
+        meta = {"kernel": "rmsnorm_silu", "flops": 0.0, "bytes": 2.0 * rows * n * (3 if identity is not None else 2)}
+        self._add(lambda s, raw=raw, out=out, identity=identity: lib.vdmi_rmsnorm_silu(
+            raw.data_ptr(), n, out.data_ptr(), n, rows, n, _ptr(gain), bstride, _ptr(shift), bstride,
+            self.F * h * w, float(n) ** 0.5, _ptr(identity), identity.shape[1] if identity is not None else 0, s),
+            meta, name + ".norm")
+        if res is not None and res[0] == "conv":
+            _, rpack, rbias, rsrcs = res
+            (r0, rc0), (r1, rc1) = rsrcs[0], (rsrcs[1] if len(rsrcs) > 1 else (None, 0))
+            y = self._buf(rows, n)
+            b = self._base_args(frames, h, w, y, n, EPI_PLAIN)
+            _fill_pass(b.main, r0, rc0, r1, rc1, h, w, 1, [(0, 0)], rpack.data)
+            b.bias = _ptr(rbias)
+            b.has_res, b.res_identity, b.ld_res = 2, _ptr(out), n
+            b.tile_bn = rpack.tile_bn
+            self._tapgemm(b, name + ".res")
+            return y
         return out
 
     def _resnet(self, name, rb, srcs, h, w) -> torch.Tensor:
@@ -415,15 +459,18 @@ class UnetEngine:
     def _pack_resnet(self, rb, device, cin_split, stacked):
         cin0, cin1 = cin_split
         d = {}
-        d["w1"] = PackedTaps(self._conv_w(rb.block1.proj.weight), cin0, cin1, EPI_NORM_SILU, device)
+        # wide layers (small images): split-channel conv + separate norm kernel, see Plan._block_split
+        split = rb.block1.proj.weight.shape[0] >= SPLIT_MIN_CHANNELS
+        epi, tbn = (EPI_PLAIN, 64) if split else (EPI_NORM_SILU, 0)
+        d["w1"] = PackedTaps(self._conv_w(rb.block1.proj.weight), cin0, cin1, epi, device, tile_bn=tbn)
         d["b1"] = rb.block1.proj.bias.detach().float().to(device).contiguous()
         cmid = d["w1"].n
-        d["w2"] = PackedTaps(self._conv_w(rb.block2.proj.weight), cmid, 0, EPI_NORM_SILU, device)
+        d["w2"] = PackedTaps(self._conv_w(rb.block2.proj.weight), cmid, 0, epi, device, tile_bn=tbn)
         d["b2"] = rb.block2.proj.bias.detach().float().to(device).contiguous()
         d["gamma1"] = rb.block1.norm.gamma.detach().float().reshape(-1).to(device).contiguous()
         d["gamma2"] = rb.block2.norm.gamma.detach().float().reshape(-1).to(device).contiguous()
         if isinstance(rb.res_conv, torch.nn.Conv3d):
-            d["wres"] = PackedTaps(self._conv_w(rb.res_conv.weight), cin0, cin1, EPI_NORM_SILU, device)
+            d["wres"] = PackedTaps(self._conv_w(rb.res_conv.weight), cin0, cin1, epi, device)
             d["bres"] = rb.res_conv.bias.detach().float().to(device).contiguous()
         else:
             d["wres"], d["bres"] = None, None
