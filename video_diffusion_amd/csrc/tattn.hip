@@ -19,7 +19,11 @@
 //
 // Output channels are permuted (through Wout's row order) so that a lane ends up with 8
 // consecutive channels per register pair: 16-byte stores, and the residual x is re-read with the
-// same 16-byte pattern.  Weights are the only LDS traffic: one head's slice, double buffered.
+// same 16-byte pattern.  Weights are the only LDS traffic.  When all heads' slices fit in LDS at once
+// (RES: C <= 64 with 8 heads) a persistent workgroup loads them once and its waves then run with no
+// barrier at all; otherwise one head's slice is double buffered with a barrier per head.
+// Scores are kept in the log2 domain (q scale and bias table pre-multiplied by log2 e) so the
+// softmax is one subtract and one v_exp_f32 per element.
 #include "vdmi_common.h"
 #include <cstring>
 
@@ -49,27 +53,38 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
     return f;
 }
 
-template <int C>
-__global__ __launch_bounds__(512, 2) void tattn_fused_kernel(const TAttnArgs a) {
+template <int C, bool RES, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArgs a) {
     constexpr int KS = C / 16, CT = C / 32, NFRAG = 3 * KS + 2 * CT, SLICE = NFRAG * 512;
-    constexpr int WP = (SLICE / 8 + 511) / 512;          // 16-byte pieces per thread per slice
+    constexpr int NTHR = NWAVES * 64;
+    constexpr int WP = (SLICE / 8 + NTHR - 1) / NTHR;    // 16-byte pieces per thread per slice
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* wbuf = reinterpret_cast<__bf16*>(smem);      // [2][SLICE]
-    float* biasl = reinterpret_cast<float*>(smem + 2 * SLICE * 2);
+    __bf16* wbuf = reinterpret_cast<__bf16*>(smem);      // RES: [heads][SLICE], else [2][SLICE]
+    float* biasl = reinterpret_cast<float*>(smem + (RES ? a.heads : 2) * SLICE * 2);
+    constexpr float LOG2E = 1.4426950408889634f;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int F = a.F, g = a.sites_per_group;
 
-    for (int i = tid; i < a.heads * F * F; i += 512) biasl[i] = a.bias ? a.bias[i] : 0.f;
+    // bias table expanded to the 32 key rows of a group: [head][query frame][key row], times log2 e
+    for (int i = tid; i < a.heads * F * 32; i += NTHR) {
+        const int row = i & 31, hq = i >> 5;
+        biasl[i] = a.bias ? a.bias[hq * F + row % F] * LOG2E : 0.f;
+    }
+    if constexpr (RES) {
+        const int pieces = a.heads * SLICE / 8;
+        for (int i = tid; i < pieces; i += NTHR)
+            *reinterpret_cast<bf16x8*>(wbuf + i * 8) = *reinterpret_cast<const bf16x8*>(a.w + i * 8);
+        __syncthreads();      // the only barrier of the kernel
+    }
+    const float qs = a.q_scale * LOG2E;
 
     // per-lane constants: this lane's row as a query / row of x, and the 16 key rows of its registers
     const int q_site = l31 / F, q_f = l31 - q_site * F;
-    int kf[16];
     unsigned kmask = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, half), ks = row / F;
-        kf[r] = row - ks * F;
+        const int ks = acc_row(r, half) / F;
         if (ks == q_site && ks < g) kmask |= 1u << r;
     }
     f32x4 rc[2], rs[2];
@@ -89,23 +104,23 @@ __global__ __launch_bounds__(512, 2) void tattn_fused_kernel(const TAttnArgs a) 
         const __bf16* p = a.w + (long long)head * SLICE;
 #pragma unroll
         for (int k = 0; k < WP; ++k) {
-            const int idx = tid + k * 512;
+            const int idx = tid + k * NTHR;
             if (idx * 8 < SLICE) wreg[k] = *reinterpret_cast<const bf16x8*>(p + idx * 8);
         }
     };
     auto store_slice = [&](__bf16* dst) {
 #pragma unroll
         for (int k = 0; k < WP; ++k) {
-            const int idx = tid + k * 512;
+            const int idx = tid + k * NTHR;
             if (idx * 8 < SLICE) *reinterpret_cast<bf16x8*>(dst + idx * 8) = wreg[k];
         }
     };
 
-    const int rounds = (a.ngroups + 7) / 8;
+    const int rounds = (a.ngroups + NWAVES - 1) / NWAVES;
     int step = 0;   // counts head iterations over the whole kernel (buffer parity)
-    load_slice(0);
+    if constexpr (!RES) load_slice(0);
     for (int round = blockIdx.x; round < rounds; round += gridDim.x) {
-        const int grp = round * 8 + wave;
+        const int grp = round * NWAVES + wave;
         const int b = grp / a.groups_per_sample;
         const int s = (grp - b * a.groups_per_sample) * g + q_site;      // site within the sample
         const bool rowvalid = grp < a.ngroups && q_site < g && s < a.HW;
@@ -137,19 +152,23 @@ __global__ __launch_bounds__(512, 2) void tattn_fused_kernel(const TAttnArgs a) 
             for (int r = 0; r < 16; ++r) oacc[ct][r] = 0.f;
 
         for (int head = 0; head < a.heads; ++head, ++step) {
-            __bf16* wb = wbuf + (step & 1) * SLICE;
-            store_slice(wb);
-            __syncthreads();
-            {   // prefetch the next slice (next head, or head 0 of this block's next round)
+            const __bf16* wb;
+            if constexpr (RES) {
+                wb = wbuf + head * SLICE;
+            } else {
+                __bf16* wd = wbuf + (step & 1) * SLICE;
+                store_slice(wd);
+                __syncthreads();
+                // prefetch the next slice (next head, or head 0 of this block's next round)
                 const int nh = head + 1 < a.heads ? head + 1 : 0;
                 if (head + 1 < a.heads || round + (int)gridDim.x < rounds) load_slice(nh);
+                wb = wd;
             }
             const __bf16* wfrag = wb + lane * 8;
 
             // ---- projections ----------------------------------------------------------------------
-            f32x16 q, k, v;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) q[r] = k[r] = v[r] = 0.f;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 q = zero, k = zero, v = zero;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 wq = *reinterpret_cast<const bf16x8*>(wfrag + (0 * KS + ks) * 512);
@@ -159,47 +178,48 @@ __global__ __launch_bounds__(512, 2) void tattn_fused_kernel(const TAttnArgs a) 
                 k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk, xh[ks], k, 0, 0, 0);
                 v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[ks], wv, v, 0, 0, 0);
             }
-            // q scale + half-split rotary (feature d pairs with d+16 = register r with r+8)
+            // q scale (times log2 e) + half-split rotary (feature d pairs with d+16 = register r with r+8)
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * rg + e;
-                    const float q1 = q[r] * a.q_scale, q2 = q[r + 8] * a.q_scale;
-                    q[r] = q1 * rc[rg][e] - q2 * rs[rg][e];
-                    q[r + 8] = q2 * rc[rg][e] + q1 * rs[rg][e];
+                    const float cq = rc[rg][e] * qs, sq = rs[rg][e] * qs;
+                    const float q1 = q[r], q2 = q[r + 8];
+                    q[r] = q1 * cq - q2 * sq;
+                    q[r + 8] = q2 * cq + q1 * sq;
                     const float k1 = k[r], k2 = k[r + 8];
                     k[r] = k1 * rc[rg][e] - k2 * rs[rg][e];
                     k[r + 8] = k2 * rc[rg][e] + k1 * rs[rg][e];
                 }
             // ---- S^T = K Q^T, softmax over keys (this lane's 16 registers + the other half) --------
-            f32x16 st;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 0), acc_frag(q, 0), st, 0, 0, 0);
+            f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 0), acc_frag(q, 0), zero, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 1), acc_frag(q, 1), st, 0, 0, 0);
-            const float* bl = biasl + (head * F + q_f) * F;
+            const float* bl = biasl + (head * F + q_f) * 32 + 4 * half;
             float mx = -1e30f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float sv = (kmask >> r) & 1u ? st[r] + bl[kf[r]] : -1e30f;
-                st[r] = sv;
-                mx = fmaxf(mx, sv);
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 8 * u);     // key rows of registers 4u..4u+3
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * u + e;
+                    // keys of other sites (and padding rows) get -1e30: exp2 below turns them into exact zeros
+                    const float sv = st[r] + ((kmask >> r) & 1u ? b4[e] : -1e30f);
+                    st[r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float lsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = (kmask >> r) & 1u ? __expf(st[r] - mx) : 0.f;
+                const float p = __builtin_amdgcn_exp2f(st[r] - mx);
                 st[r] = p;
                 lsum += p;
             }
             lsum += __shfl_xor(lsum, 32);
             // ---- O^T = V^T P^T ---------------------------------------------------------------------
-            f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.f;
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(v, 0), acc_frag(st, 0), o, 0, 0, 0);
+            f32x16 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(v, 0), acc_frag(st, 0), zero, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(v, 1), acc_frag(st, 1), o, 0, 0, 0);
             const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
 #pragma unroll
@@ -294,28 +314,35 @@ extern "C" int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const
     a.ngroups = b * a.groups_per_sample;
     a.q_scale = q_scale;
     a.eps = eps;
-    const int rounds = (a.ngroups + 7) / 8;
-    const int grid = rounds < 256 ? rounds : 256;
     const int nfrag = 3 * (c / 16) + 2 * (c / 32);
-    const size_t lds = (size_t)2 * nfrag * 1024 + (size_t)heads * f * f * 4;
+    const size_t bias_bytes = (size_t)heads * f * 32 * 4;
+    // all heads resident (and 12 waves per workgroup, 3 per SIMD) when they fit beside the bias table
+    const size_t lds_res = (size_t)heads * nfrag * 1024 + bias_bytes, lds_dbuf = (size_t)2 * nfrag * 1024 + bias_bytes;
+    const bool res = c <= 64 && lds_res <= 150 * 1024;
+    const size_t lds = res ? lds_res : lds_dbuf;
     if (lds > 160 * 1024) return VDMI_E_LDS;
+    const int nwaves = res ? 12 : 8;
+    const int rounds = (a.ngroups + nwaves - 1) / nwaves;
+    const int grid = rounds < 256 ? rounds : 256;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define VDMI_TATTN_CASE(C_)                                                                                   \
-    if (c == C_) {                                                                                            \
+#define VDMI_TATTN_CASE(C_, RES_, NW_)                                                                        \
+    if (c == C_ && res == RES_) {                                                                             \
         static bool attr_done = false;                                                                        \
         if (!attr_done) {                                                                                     \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<C_>),                    \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<C_, RES_, NW_>),         \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)    \
                 return VDMI_E_LAUNCH;                                                                         \
             attr_done = true;                                                                                 \
         }                                                                                                     \
-        hipLaunchKernelGGL(tattn_fused_kernel<C_>, dim3(grid), dim3(512), lds, st, a);                        \
+        hipLaunchKernelGGL((tattn_fused_kernel<C_, RES_, NW_>), dim3(grid), dim3(NW_ * 64), lds, st, a);      \
         VDMI_LAUNCH_CHECK();                                                                                  \
         return VDMI_OK;                                                                                       \
     }
-    VDMI_TATTN_CASE(32)
-    VDMI_TATTN_CASE(64)
-    VDMI_TATTN_CASE(128)
+    VDMI_TATTN_CASE(32, true, 12)
+    VDMI_TATTN_CASE(64, true, 12)
+    VDMI_TATTN_CASE(32, false, 8)
+    VDMI_TATTN_CASE(64, false, 8)
+    VDMI_TATTN_CASE(128, false, 8)
 #undef VDMI_TATTN_CASE
     return VDMI_E_SHAPE;
 }
