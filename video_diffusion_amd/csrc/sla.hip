@@ -44,8 +44,10 @@ struct SlaArgs {
 // ------------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(512, 2) void sla_pass1_kernel(const SlaArgs a) {
-    constexpr int KS = C / 16, PPR = C / 8, XROW = C + 8, PIECES = 32 * PPR;
-    __shared__ __attribute__((aligned(16))) __bf16 xs[2][32 * XROW];
+    constexpr int KS = C / 16, PPR = C / 8, XROW = C + 8;
+    constexpr int SUB = 4;                                    // 32-row chunks staged per barrier
+    constexpr int PIECES = SUB * 32 * PPR, LP = (PIECES + 511) / 512;   // 16-byte pieces per stage / per thread
+    __shared__ __attribute__((aligned(16))) __bf16 xs[2][SUB * 32 * XROW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int frame = blockIdx.x / a.nparts, part = blockIdx.x - frame * a.nparts;
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(512, 2) void sla_pass1_kernel(const SlaArgs a) {
     const int head = wave;
     const bool active = head < a.heads;
 
+    // Wk rows carry a factor log2 e (host packing), so exp2 of the projected k is exp of the reference's k
     bf16x8 wk[KS], wv[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -65,77 +68,89 @@ __global__ __launch_bounds__(512, 2) void sla_pass1_kernel(const SlaArgs a) {
         }
     }
 
-    // loader role: thread tid < PIECES owns 8 channels of one row of the chunk
-    const bool loader = tid < PIECES;
-    const int lrow = tid / PPR, lpiece = tid % PPR;
+    // loader role: piece p = tid + k * 512 of a stage is 8 channels of row p / PPR
     const long long fbase = (long long)frame * a.hw;
-    auto load_piece = [&](int chunk) -> bf16x8 {
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int n = chunk * 32 + lrow;
-        if (loader && n < a.hw) v = *reinterpret_cast<const bf16x8*>(a.x + (fbase + n) * C + lpiece * 8);
-        return v;
+    bf16x8 pre[LP];
+    auto load_stage = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < LP; ++k) {
+            const int p = tid + k * 512, n = c * 32 + p / PPR;
+            pre[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (p < PIECES && n < a.hw && n < c1 * 32)
+                pre[k] = *reinterpret_cast<const bf16x8*>(a.x + (fbase + n) * C + (p % PPR) * 8);
+        }
     };
-    auto norm_store = [&](bf16x8 v, __bf16* dst) {
-        float s1 = 0.f, s2 = 0.f;
+    auto norm_store = [&](__bf16* dst) {      // channel LayerNorm of each row (its PPR pieces sit in adjacent lanes)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
+        for (int k = 0; k < LP; ++k) {
+            const int p = tid + k * 512;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int m = 1; m < PPR; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
-        const float mean = s1 * (1.0f / C);
-        const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
-        bf16x8 o;
+            for (int e = 0; e < 8; ++e) { const float f = (float)pre[k][e]; s1 += f; s2 += f * f; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(((float)v[e] - mean) * rstd);
-        if (loader) *reinterpret_cast<bf16x8*>(dst + lrow * XROW + lpiece * 8) = o;
+            for (int m = 1; m < PPR; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+            const float mean = s1 * (1.0f / C);
+            const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(((float)pre[k][e] - mean) * rstd);
+            if (p < PIECES) *reinterpret_cast<bf16x8*>(dst + (p / PPR) * XROW + (p % PPR) * 8) = o;
+        }
     };
 
-    f32x16 ctx;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 ctx = zero;
+    float m_run = -1e30f, l_run = 0.f;      // running max (log2 domain) and sum of this lane's feature
 
-    bf16x8 pre = load_piece(c0);
-    for (int c = c0; c < c1; ++c) {
-        __bf16* xb = xs[(c - c0) & 1];
-        norm_store(pre, xb);
+    load_stage(c0);
+    int buf = 0;
+    for (int cs = c0; cs < c1; cs += SUB, buf ^= 1) {
+        __bf16* xb = xs[buf];
+        norm_store(xb);
         __syncthreads();
-        if (c + 1 < c1) pre = load_piece(c + 1);
-
-        f32x16 kacc, vacc;
+        if (cs + SUB < c1) load_stage(cs + SUB);
+        const int nsub = min(SUB, c1 - cs);
+        for (int u = 0; u < nsub; ++u) {
+            const int c = cs + u;
+            const __bf16* xr = xb + u * 32 * XROW;
+            f32x16 kacc = zero, vacc = zero;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) kacc[r] = vacc[r] = 0.f;
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 xa = *reinterpret_cast<const bf16x8*>(xr + l31 * XROW + ks * 16 + 8 * half);
+                kacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wk[ks], kacc, 0, 0, 0);
+                vacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wv[ks], vacc, 0, 0, 0);
+            }
+            // rows (positions) are in the registers, the head's feature d is this lane's column
+            if (c * 32 + 32 > a.hw) {     // ragged last chunk: rows past the frame never win the max, weigh nothing
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 xa = *reinterpret_cast<const bf16x8*>(xb + l31 * XROW + ks * 16 + 8 * half);
-            kacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wk[ks], kacc, 0, 0, 0);
-            vacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wv[ks], vacc, 0, 0, 0);
+                for (int r = 0; r < 16; ++r)
+                    if (c * 32 + acc_row(r, half) >= a.hw) kacc[r] = -1e30f;
+            }
+            float tmax = kacc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, kacc[r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            if (__any(tmax > m_run)) {    // rescale only when some feature's maximum moved (rare after the first chunks)
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ctx[r] *= alpha;
+            }
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(kacc[r] - m_run);
+                kacc[r] = e;
+                lsum += e;
+            }
+            lsum += __shfl_xor(lsum, 32);
+            l_run += lsum;
+            // ctx^T[e][d] += sum_n V[n][e] * E[n][d]
+            ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vacc, 0), acc_frag(kacc, 0), ctx, 0, 0, 0);
+            ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vacc, 1), acc_frag(kacc, 1), ctx, 0, 0, 0);
         }
-        // rows (positions) are in the registers, the head's feature d is this lane's column
-        float tmax = -1e30f;
-        unsigned vmask = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (c * 32 + acc_row(r, half) < a.hw) { vmask |= 1u << r; tmax = fmaxf(tmax, kacc[r]); }
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
-        float lsum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = (vmask >> r) & 1u ? __expf(kacc[r] - m_new) : 0.f;
-            const __bf16 eb = f2bf(e);
-            kacc[r] = (float)eb;
-            lsum += (float)eb;
-        }
-        lsum += __shfl_xor(lsum, 32);
-        l_run = l_run * alpha + lsum;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ctx[r] *= alpha;
-        // ctx^T[e][d] += sum_n V[n][e] * E[n][d]
-        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vacc, 0), acc_frag(kacc, 0), ctx, 0, 0, 0);
-        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vacc, 1), acc_frag(kacc, 1), ctx, 0, 0, 0);
     }
 
     if (active) {
@@ -159,36 +174,50 @@ __host__ __device__ inline int out_chan(int ct, int arow) {
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sla_fold_kernel(const SlaArgs a, int c) {
-    __shared__ float ctxn[32][33];   // [d][e]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ctxn = reinterpret_cast<float*>(smem);      // [32 d][33]
+    float* wsl = ctxn + 32 * 33;                       // [c][33]: this head's 32 columns of to_out
     const int tid = threadIdx.x;
     const int frame = blockIdx.x / a.heads, head = blockIdx.x - frame * a.heads;
     const int CT = c / 32, hid = a.heads * 32;
-    // combine the parts of this (frame, head): per feature d
-    for (int idx = tid; idx < 32 * 32; idx += 256) {
-        const int e = idx >> 5, d = idx & 31;
+    for (int idx = tid; idx < c * 32; idx += 256) {
+        const int co = idx >> 5, e = idx & 31;
+        wsl[co * 33 + e] = a.w_out[(long long)co * hid + head * 32 + e];
+    }
+    // combine the parts of this (frame, head), per feature d = tid & 31 (maxima are in the log2 domain)
+    {
+        const int d = tid & 31;
         float m = -1e30f;
         for (int p = 0; p < a.nparts; ++p)
             m = fmaxf(m, a.part_m[(((long long)frame * a.nparts + p) * a.heads + head) * 32 + d]);
-        float l = 0.f, s = 0.f;
+        float l = 0.f, sacc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int p = 0; p < a.nparts; ++p) {
             const long long pb = ((long long)frame * a.nparts + p) * a.heads + head;
-            const float w = __expf(a.part_m[pb * 32 + d] - m);
+            const float w = __builtin_amdgcn_exp2f(a.part_m[pb * 32 + d] - m);
             l += w * a.part_l[pb * 32 + d];
-            s += w * a.part_ctx[(pb * 32 + e) * 32 + d];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sacc[q] += w * a.part_ctx[(pb * 32 + (tid >> 5) + 8 * q) * 32 + d];
         }
-        ctxn[d][e] = s / l;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ctxn[d * 33 + (tid >> 5) + 8 * q] = sacc[q] * inv;
     }
     __syncthreads();
     __bf16* wf = a.wf + (((long long)frame * a.heads + head) * CT) * 2 * 512;
-    // element (ct, s, lane, j) = W'[out_chan(ct, lane&31)][head*32 + slot_row(s, j, lane>>5)]
-    for (int idx = tid; idx < CT * 2 * 512; idx += 256) {
-        const int j = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) & 1, ct = idx >> 10;
-        const int co = out_chan(ct, lane & 31), d = slot_row(s, j, lane >> 5);
-        const float* wr = a.w_out + (long long)co * hid + head * 32;
-        float acc = 0.f;
+    // element (ct, s, lane, j) = W'[out_chan(ct, lane&31)][head*32 + slot_row(s, j, lane>>5)]; a thread writes 8 j
+    for (int idx = tid; idx < CT * 2 * 64; idx += 256) {
+        const int lane = idx & 63, s = (idx >> 6) & 1, ct = idx >> 7;
+        const float* wr = wsl + out_chan(ct, lane & 31) * 33;
+        bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) acc += wr[e] * ctxn[d][e];
-        wf[idx] = f2bf(acc);
+        for (int j = 0; j < 8; ++j) {
+            const float* cr = ctxn + slot_row(s, j, lane >> 5) * 33;
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) acc += wr[e] * cr[e];
+            o[j] = f2bf(acc);
+        }
+        *reinterpret_cast<bf16x8*>(wf + idx * 8) = o;
     }
 }
 
@@ -244,9 +273,7 @@ __global__ __launch_bounds__(512, 2) void sla_pass2_kernel(const SlaArgs a) {
             for (int r = 0; r < 16; ++r) oacc[ct][r] = 0.f;
 
         for (int head = 0; head < a.heads; ++head) {
-            f32x16 q;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) q[r] = 0.f;
+            f32x16 q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 w = *reinterpret_cast<const bf16x8*>(wq + (head * KS + ks) * 512 + lane * 8);
@@ -257,9 +284,9 @@ __global__ __launch_bounds__(512, 2) void sla_pass2_kernel(const SlaArgs a) {
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, q[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f;
+            float sum = 0.f;      // Wq rows carry a factor log2 e (host packing)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { q[r] = __expf(q[r] - mx); sum += q[r]; }
+            for (int r = 0; r < 16; ++r) { q[r] = __builtin_amdgcn_exp2f(q[r] - mx); sum += q[r]; }
             sum += __shfl_xor(sum, 32);
             const float inv = a.q_scale / sum;
 #pragma unroll
@@ -319,22 +346,26 @@ extern "C" size_t vdmi_pack_sla_elems(int c, int heads) { return (size_t)heads *
 
 // HOST.  wqkv: float [3*heads*32][c] (LayerNorm gamma folded in).  out: k,v fragments
 // [heads][2][c/16][64][8] followed by q fragments [heads][c/16][64][8].
+// The q and k rows, which only ever feed a softmax, are scaled by log2 e so the kernels exponentiate with
+// exp2 alone.
 extern "C" int vdmi_pack_sla(const float* wqkv, int c, int heads, uint16_t* out) {
     if (!wqkv || !out) return VDMI_E_ARG;
     if (c <= 0 || c % 32 || heads <= 0) return VDMI_E_SHAPE;
     const int KS = c / 16, hid = heads * 32;
+    const float log2e = 1.4426950408889634f;
     size_t o = 0;
     for (int h = 0; h < heads; ++h)
         for (int t = 1; t <= 2; ++t)
             for (int ks = 0; ks < KS; ++ks)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j)
-                        out[o++] = host_bf16(wqkv[(size_t)(t * hid + h * 32 + (lane & 31)) * c + ks * 16 + 8 * (lane >> 5) + j]);
+                        out[o++] = host_bf16((t == 1 ? log2e : 1.0f) *
+                                             wqkv[(size_t)(t * hid + h * 32 + (lane & 31)) * c + ks * 16 + 8 * (lane >> 5) + j]);
     for (int h = 0; h < heads; ++h)
         for (int ks = 0; ks < KS; ++ks)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j)
-                    out[o++] = host_bf16(wqkv[(size_t)(h * 32 + (lane & 31)) * c + ks * 16 + 8 * (lane >> 5) + j]);
+                    out[o++] = host_bf16(log2e * wqkv[(size_t)(h * 32 + (lane & 31)) * c + ks * 16 + 8 * (lane >> 5) + j]);
     return VDMI_OK;
 }
 
@@ -391,7 +422,8 @@ extern "C" int vdmi_sla_fused(const void* x, void* y, const void* wpack, const f
         }                                                                                                     \
         hipLaunchKernelGGL(sla_pass1_kernel<C_>, grid, dim3(512), 0, st, a);                                  \
         VDMI_LAUNCH_CHECK();                                                                                  \
-        hipLaunchKernelGGL(sla_fold_kernel, dim3((unsigned)(frames * heads)), dim3(256), 0, st, a, c);        \
+        hipLaunchKernelGGL(sla_fold_kernel, dim3((unsigned)(frames * heads)), dim3(256),                      \
+                           (size_t)(32 + C_) * 33 * 4, st, a, c);                                             \
         VDMI_LAUNCH_CHECK();                                                                                  \
         hipLaunchKernelGGL(sla_pass2_kernel<C_>, grid, dim3(512), lds2, st, a);                               \
         VDMI_LAUNCH_CHECK();                                                                                  \
