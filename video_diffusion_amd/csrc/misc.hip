@@ -69,34 +69,46 @@ __global__ __launch_bounds__(256) void init_conv_kernel(const float* __restrict_
     }
 }
 
-// final 1x1 conv: bf16 rows -> float32 channels-first.  One lane per pixel.
+// final 1x1 conv: bf16 rows -> float32 channels-first.  A row's cin/8 16-byte pieces sit on adjacent
+// lanes (whole rows per wave instruction); each lane's partial dot products are combined by a butterfly.
+template <int LPR>
 __global__ __launch_bounds__(256) void final_conv_kernel(const __bf16* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          long long rows, int cin, int nf, long long hw, int cout) {
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= rows) return;
+    constexpr int RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long long m = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const long long mr = m < rows ? m : rows - 1;
     float acc[8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = (o < cout && bias) ? bias[o] : 0.f;
-    const bf16x8* ip = reinterpret_cast<const bf16x8*>(in + m * cin);
-    for (int c8 = 0; c8 < cin / 8; ++c8) {
-        const bf16x8 t = ip[c8];
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    for (int c8 = sub; c8 < cin / 8; c8 += LPR) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(in + mr * cin + c8 * 8);
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
 #pragma unroll
         for (int o = 0; o < 8; ++o)
             if (o < cout) {
-                const float* wr = w + (size_t)o * cin + c8 * 8;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + (size_t)o * cin + c8 * 8);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + (size_t)o * cin + c8 * 8 + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[o] += v[e] * wr[e];
+                for (int e = 0; e < 4; ++e) acc[o] += v[e] * w0[e] + v[4 + e] * w1[e];
             }
     }
-    const long long frame = m / hw, s = m - frame * hw;
-    const long long b = frame / nf, f = frame - b * nf;
 #pragma unroll
     for (int o = 0; o < 8; ++o)
-        if (o < cout) out[((b * cout + o) * nf + f) * hw + s] = acc[o];
+        if (o < cout) {
+#pragma unroll
+            for (int s = 1; s < LPR; s <<= 1) acc[o] += __shfl_xor(acc[o], s);
+        }
+    if (sub == 0 && m < rows) {
+        const long long frame = m / hw, sp = m - frame * hw;
+        const long long b = frame / nf, f = frame - b * nf;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < cout) out[((b * cout + o) * nf + f) * hw + sp] = acc[o] + (bias ? bias[o] : 0.f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* e0 = reinterpret_cast<float*>(smem);   // [dim]
     float* h1 = e0 + dim;                         // [8*dim]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int b = blockIdx.x;
     // gridDim.y workgroups share one batch element: each recomputes the (small) first layer and
     // produces a slice of the second layer's rows
@@ -131,23 +143,36 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
         e0[half + k] = cosf(ang);
     }
     __syncthreads();
-    for (int j = wave; j < td; j += 4) {
+    // layer 1: one thread per output row, the row read as independent 16-byte loads (dim % 4 == 0)
+    for (int j = tid; j < td; j += 256) {
+        const float* wr = w1 + (size_t)j * dim;
         float s = 0.f;
-        for (int k = lane; k < dim; k += 64) s += w1[(size_t)j * dim + k] * e0[k];
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float v = s + b1[j];
-            h1[j] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact GELU
+        for (int k = 0; k < dim; k += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+            s += wv[0] * e0[k] + wv[1] * e0[k + 1] + wv[2] * e0[k + 2] + wv[3] * e0[k + 3];
         }
+        const float v = s + b1[j];
+        h1[j] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact GELU
     }
     __syncthreads();
+    // layer 2: this workgroup's rows, 8 lanes per row (each lane every 8th 16-byte piece), butterfly
     const int rows_per = (td + nsplit - 1) / nsplit;
     const int j0 = split * rows_per, j1 = min(td, j0 + rows_per);
-    for (int j = j0 + wave; j < j1; j += 4) {
+    const int sub = tid & 7;
+    for (int jb = j0; jb < j1; jb += 32) {
+        const int j = jb + (tid >> 3);
+        const bool live = j < j1;
+        const float* wr = w2 + (size_t)(live ? j : j0) * td;
         float s = 0.f;
-        for (int k = lane; k < td; k += 64) s += w2[(size_t)j * td + k] * h1[k];
-        s = wave_sum(s);
-        if (lane == 0) {
+        for (int k = sub * 4; k < td; k += 32) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + k);
+            s += wv[0] * hv[0] + wv[1] * hv[1] + wv[2] * hv[2] + wv[3] * hv[3];
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (live && sub == 0) {
             const float v = s + b2[j];
             emb_raw[(size_t)b * ed + j] = v;
             emb_silu[(size_t)b * ed + j] = silu_f(v);
@@ -318,11 +343,21 @@ extern "C" int vdmi_final_conv(const void* in, const float* w, const float* bias
                                int h, int wd, int cout, vdmi_stream stream) {
     if (!in || !w || !out) return VDMI_E_ARG;
     if (b <= 0 || cin <= 0 || cin % 8 || f <= 0 || h <= 0 || wd <= 0 || cout <= 0 || cout > 8) return VDMI_E_SHAPE;
-    if (!aligned16(in)) return VDMI_E_ALIGN;
+    if (!aligned16(in) || !aligned16(w)) return VDMI_E_ALIGN;
     const long long rows = (long long)b * f * h * wd;
-    hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const __bf16*>(in), w, bias, out, rows, cin, f,
-                       (long long)h * wd, cout);
+    const int pieces = cin / 8;
+#define VDMI_FC_CASE(LPR_)                                                                                  \
+    {                                                                                                       \
+        const long long blocks = (rows + (256 / LPR_) - 1) / (256 / LPR_);                                  \
+        if (blocks > 0x7fffffffLL) return VDMI_E_SHAPE;                                                     \
+        hipLaunchKernelGGL(final_conv_kernel<LPR_>, dim3((unsigned)blocks), dim3(256), 0,                   \
+                           static_cast<hipStream_t>(stream), static_cast<const __bf16*>(in), w, bias, out,  \
+                           rows, cin, f, (long long)h * wd, cout);                                          \
+    }
+    if (pieces >= 8) VDMI_FC_CASE(8)
+    else if (pieces >= 4) VDMI_FC_CASE(4)
+    else VDMI_FC_CASE(1)
+#undef VDMI_FC_CASE
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
@@ -331,8 +366,9 @@ extern "C" int vdmi_time_embed(const int64_t* t, int b, int dim, const float* w1
                                const float* b2, const float* cond, const float* null_cond, const uint8_t* null_mask,
                                int cond_dim, float* emb_silu, float* emb_raw, vdmi_stream stream) {
     if (!t || !w1 || !b1 || !w2 || !b2 || !emb_silu || !emb_raw) return VDMI_E_ARG;
-    if (b <= 0 || dim < 4 || dim % 2 || cond_dim < 0) return VDMI_E_SHAPE;
+    if (b <= 0 || dim < 4 || dim % 4 || cond_dim < 0) return VDMI_E_SHAPE;
     if (cond_dim > 0 && (!cond || (null_mask && !null_cond))) return VDMI_E_ARG;
+    if (!aligned16(w1) || !aligned16(w2)) return VDMI_E_ALIGN;
     const size_t lds = (size_t)9 * dim * 4;
     if (lds > 64 * 1024) return VDMI_E_LDS;
     hipLaunchKernelGGL(time_embed_kernel, dim3((unsigned)b, 16u), dim3(256), lds, static_cast<hipStream_t>(stream), t, dim,
