@@ -69,6 +69,129 @@ __global__ __launch_bounds__(256) void init_conv_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// init conv on the matrix cores (cout a multiple of 32): the k*k*cin taps are the contraction axis,
+// padded to a multiple of 16.  Both operands are split into bf16 high and low parts
+// (x = xh + xl, w = wh + wl) and y = wh*xh + wh*xl + wl*xh is accumulated in fp32, which keeps the
+// result within ~2^-16 of the fp32 convolution before the single rounding to bf16.
+// One workgroup per 16x16 pixel tile of one frame, a wave per 64 pixels; the weight fragments
+// (rows permuted so a lane ends up with 8 consecutive channels per register pair), the haloed fp32
+// patch and the tap -> patch offset table live in LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ic_out_chan(int ct, int arow) {
+    const int u = arow >> 3, hh = (arow >> 2) & 1, vv = arow & 3;
+    return 32 * ct + 16 * (u >> 1) + 8 * hh + 4 * (u & 1) + vv;
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void init_conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, __bf16* __restrict__ out,
+                                                             int cin, int nf, int h, int wd, int ks, int nks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cout = CT * 32, kk = ks * ks, ktot = cin * kk, pdim = 16 + ks - 1, pad = ks / 2;
+    __bf16* wh = reinterpret_cast<__bf16*>(smem);                    // [CT][nks][64][8]
+    __bf16* wl = wh + CT * nks * 512;
+    int* toff = reinterpret_cast<int*>(wl + CT * nks * 512);         // [nks*16] patch offset of tap k
+    float* pl = reinterpret_cast<float*>(toff + nks * 16);           // [cin][pdim][pdim]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tiles_x = (wd + 15) / 16, ntiles = tiles_x * ((h + 15) / 16);
+    const int frame = blockIdx.y, b = frame / nf, f = frame % nf;
+
+    for (int idx = tid; idx < CT * nks * 512; idx += 256) {
+        const int j = idx & 7, ln = (idx >> 3) & 63, s = (idx >> 9) % nks, ct = idx / (512 * nks);
+        const int k = s * 16 + 8 * (ln >> 5) + j, co = ic_out_chan(ct, ln & 31);
+        const float v = k < ktot ? w[(size_t)co * ktot + k] : 0.f;
+        const __bf16 hi = f2bf(v);
+        wh[idx] = hi;
+        wl[idx] = f2bf(v - (float)hi);
+    }
+    for (int k = tid; k < nks * 16; k += 256) {
+        int o = 0;                                   // padded taps read element 0 (their weights are zero)
+        if (k < ktot) {
+            const int ci = k / kk, r = k - ci * kk, ky = r / ks, kx = r - ky * ks;
+            o = (ci * pdim + ky) * pdim + kx;
+        }
+        toff[k] = o;
+    }
+    // a workgroup converts the weights once and then walks gridDim.x-strided tiles of its frame
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ty = tile / tiles_x, tx = tile % tiles_x;
+    __syncthreads();      // the previous tile's patch has been consumed
+    const int y0 = ty * 16 - pad, x0 = tx * 16 - pad;
+    for (int idx = tid; idx < cin * pdim * pdim; idx += 256) {
+        const int ci = idx / (pdim * pdim), rem = idx % (pdim * pdim);
+        const int iy = y0 + rem / pdim, ix = x0 + rem % pdim;
+        float v = 0.f;
+        if (iy >= 0 && iy < h && ix >= 0 && ix < wd)
+            v = x[(((size_t)b * cin + ci) * nf + f) * h * wd + (size_t)iy * wd + ix];
+        pl[idx] = v;
+    }
+    __syncthreads();
+
+    f32x16 acc[CT][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][j][r] = 0.f;
+    int pbase[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wave * 64 + j * 32 + l31;       // pixel of the tile: row p >> 4, column p & 15
+        pbase[j] = (p >> 4) * pdim + (p & 15);
+    }
+    for (int s = 0; s < nks; ++s) {
+        int to[8];
+        {
+            const int* tp = toff + s * 16 + 8 * half;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { to[e] = __float_as_int(t0[e]); to[4 + e] = __float_as_int(t1[e]); }
+        }
+        bf16x8 xh[2], xl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = pl[pbase[j] + to[e]];
+                const __bf16 hi = f2bf(v);
+                xh[j][e] = hi;
+                xl[j][e] = f2bf(v - (float)hi);
+            }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wh + ((ct * nks + s) * 64 + lane) * 8);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(wl + ((ct * nks + s) * 64 + lane) * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[ct][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[j], acc[ct][j], 0, 0, 0);
+                acc[ct][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[j], acc[ct][j], 0, 0, 0);
+                acc[ct][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[j], acc[ct][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wave * 64 + j * 32 + l31;
+        const int oy = ty * 16 + (p >> 4), ox = tx * 16 + (p & 15);
+        if (oy < h && ox < wd) {
+            const size_t orow = ((size_t)frame * h + oy) * wd + ox;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int kl = 0; kl < 2; ++kl) {
+                    const int ch = (2 * ct + kl) * 16 + 8 * half;
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[ct][j][8 * kl + e] + (bias ? bias[ch + e] : 0.f));
+                    *reinterpret_cast<bf16x8*>(out + orow * cout + ch) = o;
+                }
+        }
+    }
+    }
+}
+
 // final 1x1 conv: bf16 rows -> float32 channels-first.  A row's cin/8 16-byte pieces sit on adjacent
 // lanes (whole rows per wave instruction); each lane's partial dot products are combined by a butterfly.
 template <int LPR>
@@ -323,6 +446,32 @@ extern "C" int vdmi_init_conv(const float* x, const float* w, const float* bias,
         return VDMI_E_SHAPE;
     if (!aligned16(out)) return VDMI_E_ALIGN;
     const int pdim = 16 + ksize - 1;
+    const dim3 tile_grid((unsigned)(((h + 15) / 16) * ((wd + 15) / 16)), (unsigned)(b * f));
+    if (cout == 32 || cout == 64 || cout == 128) {
+        const int nks = (cin * ksize * ksize + 15) / 16, ct = cout / 32;
+        const size_t mlds = (size_t)2 * ct * nks * 1024 + (size_t)nks * 64 + (size_t)cin * pdim * pdim * 4;
+        if (mlds <= 160 * 1024) {
+#define VDMI_IC_CASE(CT_)                                                                                    \
+    if (ct == CT_) {                                                                                         \
+        static bool done = false;                                                                            \
+        if (!done) {                                                                                         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(init_conv_mfma_kernel<CT_>),               \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)   \
+                return VDMI_E_LAUNCH;                                                                        \
+            done = true;                                                                                     \
+        }                                                                                                    \
+        hipLaunchKernelGGL(init_conv_mfma_kernel<CT_>, dim3((tile_grid.x + 3) / 4, tile_grid.y), dim3(256), mlds, \
+                           static_cast<hipStream_t>(stream), x, w, bias, static_cast<__bf16*>(out), cin, f,  \
+                           h, wd, ksize, nks);                                                               \
+        VDMI_LAUNCH_CHECK();                                                                                 \
+        return VDMI_OK;                                                                                      \
+    }
+            VDMI_IC_CASE(1)
+            VDMI_IC_CASE(2)
+            VDMI_IC_CASE(4)
+#undef VDMI_IC_CASE
+        }
+    }
     const size_t lds = ((size_t)cin * ksize * ksize * cout + (size_t)cin * pdim * pdim) * 4;
     if (lds > 160 * 1024) return VDMI_E_LDS;
     static bool attr_done = false;
