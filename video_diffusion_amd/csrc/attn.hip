@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void sla_context_kernel(const __bf16* __restri
                                                           __bf16* __restrict__ w_folded) {
     __shared__ __attribute__((aligned(16))) __bf16 Ek[32 * SLA_ROW];
     __shared__ __attribute__((aligned(16))) __bf16 Vv[32 * SLA_ROW];
-    __shared__ float ctx[4][32][33];
+    __shared__ __attribute__((aligned(16))) float ctx[4][32][33];
     __shared__ float rowmax[32], rowsum[32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,19 +158,42 @@ __global__ __launch_bounds__(256) void sla_context_kernel(const __bf16* __restri
     }
     __syncthreads();
 
-    // fold into the output projection and write in vdmi_pack_taps order (1 tap, cin = heads*32)
+    // fold into the output projection and write in vdmi_pack_taps order (1 tap, cin = heads*32).
+    // Work item = (output channel, group of 8 features d): 8 consecutive d are 8 consecutive k of one
+    // fragment, i.e. one 16-byte store.  The normalised context is re-laid as [e][d] so 8 d are two
+    // 16-byte LDS reads.
+    float* ctxT = &ctx[1][0][0];                 // [32 e][32 d], reuses the partial-sum planes
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        const int d = idx >> 5, e = idx & 31;
+        ctxT[e * 32 + d] = ctx[0][d][e];
+    }
+    __syncthreads();
     __bf16* wf = w_folded + (long long)frame * hid * cpad;
     const int ksper = bkc / 16, ctn = cpad / 32;
-    for (int idx = tid; idx < c * 32; idx += 256) {
-        const int co = idx >> 5, d = idx & 31;
+    for (int item = tid; item < c * 4; item += 256) {
+        const int co = item >> 2, dg = item & 3;
         const float* wr = w_out + (long long)co * hid + hd * 32;
-        float s = 0.f;
+        float acc[8];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) s += wr[e] * ctx[0][d][e];
-        const int k = hd * 32 + d;
-        const int chunk = k / bkc, kin = k % bkc, ks = kin >> 4, half = (kin >> 3) & 1, j = kin & 7;
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(ctxT + (4 * q + e) * 32 + dg * 8);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(ctxT + (4 * q + e) * 32 + dg * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[j] += wv[e] * c0[j]; acc[4 + j] += wv[e] * c1[j]; }
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+        const int k = hd * 32 + dg * 8;
+        const int chunk = k / bkc, kin = k % bkc, ks = kin >> 4, half = (kin >> 3) & 1;
         const int ct = co >> 5, ln = half * 32 + (co & 31);
-        wf[((((long long)chunk * ctn + ct) * ksper + ks) * 64 + ln) * 8 + j] = f2bf(s);
+        *reinterpret_cast<bf16x8*>(wf + ((((long long)chunk * ctn + ct) * ksper + ks) * 64 + ln) * 8) = o;
     }
 }
 
@@ -198,7 +221,7 @@ extern "C" int vdmi_sla_context(const void* kvT, int frames, int heads, int hw, 
     if (frames <= 0 || heads <= 0 || hw <= 0 || c <= 0 || cpad < c || cpad % 32 || (bkc != 32 && bkc != 64) ||
         (heads * 32) % bkc)
         return VDMI_E_SHAPE;
-    if (!aligned16(kvT) || !aligned16(w_folded)) return VDMI_E_ALIGN;
+    if (!aligned16(kvT) || !aligned16(w_folded) || !aligned16(w_out)) return VDMI_E_ALIGN;
     hipLaunchKernelGGL(sla_context_kernel, dim3((unsigned)(frames * heads)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const __bf16*>(kvT), heads, hw, w_out, c, cpad,
                        bkc, static_cast<__bf16*>(w_folded));

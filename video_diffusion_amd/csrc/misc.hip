@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
     }
 }
 
-// every ResnetBlock.mlp Linear at once: one wave per (block, channel), both the scale and the shift row
+// every ResnetBlock.mlp Linear at once: one wave per (block, channel) computes the scale and the shift row
+// for 16 batch elements at a time -- lane = (batch element, quarter of the embedding), two shuffles
 __global__ __launch_bounds__(256) void block_scale_shift_kernel(const float* __restrict__ emb_silu, int nb, int emb_dim,
                                                                 const float* __restrict__ w_all, const float* __restrict__ b_all,
                                                                 const float* __restrict__ gamma_all,
@@ -320,24 +321,29 @@ __global__ __launch_bounds__(256) void block_scale_shift_kernel(const float* __r
     const int lane = threadIdx.x & 63;
     const int hr = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (hr >= half_total) return;
-    int k = 0;
-    while (k + 1 < nblocks && block_offsets[k + 1] <= hr) ++k;
+    // block of this row: the last one whose offset is <= hr (one load per lane + a ballot, nblocks <= 64)
+    const int my_off = lane < nblocks ? block_offsets[lane] : 0x7fffffff;
+    const int k = __popcll(__ballot(my_off <= hr)) - 1;
     const int off = block_offsets[k], ch = block_channels[k], c = hr - off;
     const float* wsc = w_all + (size_t)(2 * off + c) * emb_dim;
     const float* wsh = w_all + (size_t)(2 * off + ch + c) * emb_dim;
     const float bsc = b_all[2 * off + c], bsh = b_all[2 * off + ch + c];
     const float g = gamma_all[hr];
-    for (int b = 0; b < nb; ++b) {
-        const float* e = emb_silu + (size_t)b * emb_dim;
+    const int qp = lane & 3;
+    for (int b0 = 0; b0 < nb; b0 += 16) {
+        const int b = b0 + (lane >> 2);
+        const float* e = emb_silu + (size_t)(b < nb ? b : 0) * emb_dim;
         float s0 = 0.f, s1 = 0.f;
-        for (int q = lane; q < emb_dim; q += 64) {
+        for (int q = qp; q < emb_dim; q += 4) {      // lanes of one batch element interleave: whole lines per group
             const float ev = e[q];
             s0 += wsc[q] * ev;
             s1 += wsh[q] * ev;
         }
-        s0 = wave_sum(s0);
-        s1 = wave_sum(s1);
-        if (lane == 0) {
+        s0 += __shfl_xor(s0, 1);
+        s1 += __shfl_xor(s1, 1);
+        s0 += __shfl_xor(s0, 2);
+        s1 += __shfl_xor(s1, 2);
+        if (qp == 0 && b < nb) {
             gain[(size_t)b * half_total + hr] = g * (s0 + bsc + 1.0f);
             shift[(size_t)b * half_total + hr] = s1 + bsh;
         }
