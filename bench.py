@@ -170,7 +170,9 @@ def main():
             c["launches_per_step"] += d["n"] // reps
             c["flops_per_step"] += meta.get("flops", 0.0)
             c["bytes_per_step"] += meta.get("bytes", 0.0)
-        dom_key = max(classes, key=lambda k: classes[k]["ms_per_step"])
+        # dominant kernel: the matrix-core kernel class with the largest share of the step
+        mfma_classes = [k for k in classes if classes[k]["flops_per_step"] > 0]
+        dom_key = max(mfma_classes, key=lambda k: classes[k]["ms_per_step"])
         dom = classes[dom_key]
         avg_ms = dom["ms_per_step"] / dom["launches_per_step"]
         achieved = dom["flops_per_step"] / (dom["ms_per_step"] * 1e-3) / 1e12
