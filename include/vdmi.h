@@ -79,7 +79,12 @@ typedef struct vdmi_tap_pass {
     const void* w;           /* weights packed by vdmi_pack_taps (bf16)                    */
     int64_t w_group_stride;  /* elements between per-group weight sets (0: one shared set) */
     int32_t w_group_frames;  /* frames per weight group (used when w_group_stride != 0)    */
-    int32_t reserved;
+    int32_t phases;          /* 0 / 1: off.  P = out_mul*out_mul > 1 (main pass, PLAIN): the taps are P
+                                equal groups run as independent convolutions of one launch; group p uses
+                                the weight set at w + p*w_phase_stride and writes output pixel
+                                grid*out_mul + out_off + (p / out_mul, p % out_mul) -- the output
+                                parities of a stride-2 transposed conv (vdp.py:374-375)          */
+    int64_t w_phase_stride;  /* elements between the phases' weight sets                          */
 } vdmi_tap_pass;
 
 typedef struct vdmi_tapgemm_args {

@@ -23,7 +23,8 @@ class TapPass(C.Structure):
         ("dy", C.c_int8 * MAX_TAPS), ("dx", C.c_int8 * MAX_TAPS),
         ("w", C.c_void_p),
         ("w_group_stride", C.c_int64),
-        ("w_group_frames", C.c_int32), ("reserved", C.c_int32),
+        ("w_group_frames", C.c_int32), ("phases", C.c_int32),
+        ("w_phase_stride", C.c_int64),
     ]
 
 

@@ -59,6 +59,10 @@ struct PassDev {
     // frame stacking: a tile covers `fstack` whole frames of fs_rows tile rows each (images smaller than
     // the pixel tile); every frame has its own haloed band of `phf` patch rows.  fstack == 1: off.
     int fstack, fs_rows, phf, nframes;
+    // phases (main pass of a PLAIN launch): the taps are `phases` equal groups, each an independent
+    // convolution with its own weight set and output parity; blockIdx.z enumerates (frame group, phase)
+    int phases;
+    long long w_phase_stride;
 };
 
 struct KArgs {
@@ -97,7 +101,7 @@ template <int BM, int BN, int WM, int WN, int BKC, bool STATS, class Pro>
 __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32][WM / 32], __bf16* wbuf,
                                          __bf16* patch, float* stats, int frame, int ty, int tx, int ltw,
                                          int nt, int tid, float ln_eps, Pro&& after_first_loads,
-                                         unsigned long long* diag = nullptr) {
+                                         unsigned long long* diag = nullptr, int phase = 0) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32, KS = BKC / 16, PROW = BKC + 8, PPR = BKC / 8;
     constexpr int WP = BN * BKC / 8 / NT;
@@ -122,6 +126,8 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     const int iy0 = ty * TH * g.stride + g.min_dy, ix0 = tx * TW * g.stride + g.min_dx;
     const __bf16* wg = g.w + (long long)nt * BN * BKC;
     if (g.w_group_stride) wg += (long long)(frame / g.w_group_frames) * g.w_group_stride;
+    const int ntp = g.phases > 1 ? g.ntaps / g.phases : g.ntaps, tap0 = phase * ntp;   // this phase's taps
+    wg += phase * g.w_phase_stride;
 
     bf16x8 wreg[WP];
     auto load_w = [&](int s) {
@@ -136,7 +142,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
         for (int k = 0; k < KMAX; ++k) s1[k] = s2[k] = 0.f;
     }
 
-    const int nsteps = g.nch * g.ntaps;
+    const int nsteps = g.nch * ntp;
     const int total = g.ph * g.pw * PPR;
     load_w(0);
 
@@ -219,8 +225,8 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
             if (c + 1 < g.nch) patch_prefetch(c + 1);
         }
 
-        for (int t = 0; t < g.ntaps; ++t) {
-            const int s = c * g.ntaps + t;
+        for (int t = 0; t < ntp; ++t) {
+            const int s = c * ntp + t;
             __bf16* wb = wbuf + (s & 1) * BN * BKC;
             [[maybe_unused]] const unsigned long long ts0 = VDMI_STAMP_T();
 #pragma unroll
@@ -238,7 +244,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
 #if !defined(VDMI_ABL) || VDMI_ABL != 3
             if (s + 1 < nsteps) load_w(s + 1);
 #endif
-            const int to = g.toff[t] * PROW;
+            const int to = g.toff[tap0 + t] * PROW;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 af[MI], bfr[NJ];
@@ -307,7 +313,10 @@ __attribute__((amdgpu_waves_per_eu((BM >= 256 && BM / WM >= 8) ? 4 : 2))) void t
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave % NWM, wn = wave / NWM;
     const int h = lane >> 5;
     const int tile = blockIdx.x, ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int nt = blockIdx.y, frame = blockIdx.z * a.main.fstack, n0 = nt * BN;
+    const int nph = a.main.phases > 1 ? a.main.phases : 1;
+    const int phase = blockIdx.z % nph;
+    const int nt = blockIdx.y, frame = (blockIdx.z / nph) * a.main.fstack, n0 = nt * BN;
+    const int ooy = a.out_off_y + phase / a.out_mul, oox = a.out_off_x + phase % a.out_mul;
     const int TW = 1 << a.ltw, TH = BM >> a.ltw;
     // output row of tile pixel p (-1: outside the image / past the last frame)
     auto pixel_orow = [&](int p) -> long long {
@@ -320,7 +329,7 @@ __attribute__((amdgpu_waves_per_eu((BM >= 256 && BM / WM >= 8) ? 4 : 2))) void t
             if (fi >= a.main.fstack || fr >= a.main.nframes) return -1;
         }
         return (gy < a.grid_h && gx < a.grid_w)
-                   ? ((long long)fr * a.out_h + gy * a.out_mul + a.out_off_y) * a.out_w + gx * a.out_mul + a.out_off_x
+                   ? ((long long)fr * a.out_h + gy * a.out_mul + ooy) * a.out_w + gx * a.out_mul + oox
                    : -1;
     };
 
@@ -364,7 +373,7 @@ __attribute__((amdgpu_waves_per_eu((BM >= 256 && BM / WM >= 8) ? 4 : 2))) void t
 
     constexpr bool STATS = (EPI == VDMI_EPI_QKV_ATTN || EPI == VDMI_EPI_QKV_SLA);
     VDMI_STAMP(a.diag, 0);
-    run_pass<BM, BN, WM, WN, BKC, STATS>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag);
+    run_pass<BM, BN, WM, WN, BKC, STATS>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag, phase);
     VDMI_STAMP(a.diag, 2);
     if constexpr (STATS) __syncthreads();   // row statistics written by the loader threads
 
@@ -620,6 +629,9 @@ int build_pass(const vdmi_tap_pass& p, int bkc, int npad, PassDev* d) {
     d->w_group_stride = p.w_group_stride;
     d->w_group_frames = p.w_group_frames > 0 ? p.w_group_frames : 1;
     d->wtile_all = (long long)npad * bkc;
+    d->phases = p.phases > 1 ? p.phases : 1;
+    d->w_phase_stride = d->phases > 1 ? p.w_phase_stride : 0;
+    if (d->phases > 1 && (p.ntaps % d->phases || p.w_phase_stride % 8)) return VDMI_E_SHAPE;
     return VDMI_OK;
 }
 
@@ -708,6 +720,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if (epi == VDMI_EPI_QKV_SLA && (!A.out2 || A.sla_hw <= 0)) return VDMI_E_ARG;
     if (A.has_res == 2 && (!A.res_identity || A.ld_res % 8 || !aligned16(A.res_identity))) return VDMI_E_ARG;
     if (A.has_res == 1 && epi != VDMI_EPI_NORM_SILU) return VDMI_E_ARG;
+    if (A.main.phases > 1 && (epi != VDMI_EPI_PLAIN || A.main.phases != A.out_mul * A.out_mul)) return VDMI_E_ARG;
     // the loader indexes source pixels with 32-bit integers
     if ((long long)A.frames * A.main.in_h * A.main.in_w > 0x7fffffffLL) return VDMI_E_SHAPE;
 
@@ -846,6 +859,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
 #endif
         if (is_qkv && (A.n % 96)) return VDMI_E_SHAPE;
 
+        frames *= k.main.phases;    // grid.z: (frame group, phase)
         if (best_tiles > 0x7fffffffLL || frames > 65535) return VDMI_E_SHAPE;
         const dim3 grid((unsigned)best_tiles, (unsigned)(npad / c.bn), (unsigned)frames);
         if (grid.y > 65535) return VDMI_E_SHAPE;

@@ -313,14 +313,14 @@ class Plan:
         frames = self.B * self.F
         oh, ow = 2 * h, 2 * w
         y = self._buf(frames * oh * ow, c)
-        for p in (0, 1):
-            for q in (0, 1):
-                taps = [(dy, dx) for (_, dy) in _UP_PAIRS[p] for (_, dx) in _UP_PAIRS[q]]
-                a = self._base_args(frames, h, w, y, c, EPI_PLAIN, out_h=oh, out_w=ow)
-                a.out_mul, a.out_off_y, a.out_off_x = 2, p, q
-                _fill_pass(a.main, x, c, None, 0, h, w, 1, taps, up["w"][p][q].data)
-                a.bias = _ptr(up["b"])
-                self._tapgemm(a, f"{name}.phase{p}{q}")
+        # the four output parities (p, q) are four 4-tap convolutions of one launch
+        taps = [(dy, dx) for p in (0, 1) for q in (0, 1) for (_, dy) in _UP_PAIRS[p] for (_, dx) in _UP_PAIRS[q]]
+        a = self._base_args(frames, h, w, y, c, EPI_PLAIN, out_h=oh, out_w=ow)
+        a.out_mul, a.out_off_y, a.out_off_x = 2, 0, 0
+        _fill_pass(a.main, x, c, None, 0, h, w, 1, taps, up["w"])
+        a.main.phases, a.main.w_phase_stride = 4, up["phase_stride"]
+        a.bias = _ptr(up["b"])
+        self._tapgemm(a, name)
         return y
 
     # -- the forward graph ------------------------------------------------------------------
@@ -541,12 +541,13 @@ class UnetEngine:
         # ConvTranspose3d weight [cin][cout][1][4][4]; one 4-tap weight set per output parity (p, q)
         w = convt.weight.detach().float().cpu()[:, :, 0]                     # [cin][cout][4][4]
         cin = w.shape[0]
-        ws = [[None, None], [None, None]]
+        packs = []
         for p in (0, 1):
             for q in (0, 1):
                 taps = [w[:, :, ky, kx].t() for (ky, _) in _UP_PAIRS[p] for (kx, _) in _UP_PAIRS[q]]   # each [cout][cin]
-                ws[p][q] = PackedTaps(torch.stack(taps, dim=-1), cin, 0, EPI_PLAIN, device)
-        return {"w": ws, "b": convt.bias.detach().float().to(device).contiguous()}
+                packs.append(PackedTaps(torch.stack(taps, dim=-1), cin, 0, EPI_PLAIN, device).data)
+        return {"w": torch.cat(packs).contiguous(), "phase_stride": packs[0].numel(),
+                "b": convt.bias.detach().float().to(device).contiguous()}
 
     def _pack(self, device):
         u = self.unet
