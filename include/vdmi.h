@@ -85,6 +85,13 @@ typedef struct vdmi_tap_pass {
                                 grid*out_mul + out_off + (p / out_mul, p % out_mul) -- the output
                                 parities of a stride-2 transposed conv (vdp.py:374-375)          */
     int64_t w_phase_stride;  /* elements between the phases' weight sets                          */
+    int32_t space_to_depth;  /* 1: src0 is bf16 [frames*in_h*in_w][c0/4] and the pass sees its 2x2
+                                space-to-depth view: pixel (Y, X), channel (2a+b)*(c0/4) + ci is source
+                                pixel (2Y-1+a, 2X-1+b), zero outside the image.  A 4x4 / stride 2 / pad 1
+                                convolution (Downsample, vdp.py:377-378) is then the stride-1 taps
+                                (0,0),(0,1),(1,0),(1,1) over 4*C channels.  Needs stride 1, c1 = 0,
+                                (c0/4) a multiple of the input chunk, frames*in_h*in_w < 2^27.       */
+    int32_t reserved;
 } vdmi_tap_pass;
 
 typedef struct vdmi_tapgemm_args {

@@ -254,6 +254,25 @@ def test_downsample_upsample(tiny):
     assert rel_err(from_rows(y, B, Fr, H, H), O.upsample(sd, "ups.0.4", xh)) < LAYER_TOL
 
 
+@pytest.mark.parametrize("c,h,w", [(64, 12, 12), (64, 10, 14), (128, 6, 6)])
+def test_downsample_space_to_depth(tiny, c, h, w):
+    """Downsample (Conv3d (1,4,4) / stride 2 / pad 1, vdp.py:377-378) through the space-to-depth form used for
+    64-multiple channel counts, against torch's conv3d on the same bf16-rounded operands."""
+    L, B, Fr = tiny["L"], tiny["B"], tiny["F"]
+    conv = torch.nn.Conv3d(c, c, (1, 4, 4), (1, 2, 2), (0, 1, 1))
+    with torch.no_grad():
+        conv.weight.copy_(inp(f"s2d.w{c}", tuple(conv.weight.shape), scale=0.05))
+        conv.bias.copy_(inp(f"s2d.b{c}", (c,), scale=0.1))
+    dn = L.eng._pack_down(conv, dev())
+    assert dn["s2d"]
+    x = bf16_round(inp(f"s2d.x{c}.{h}.{w}", (B, c, Fr, h, w)))
+    y = L.run(lambda plan, P: plan._down("probe.down", dn, to_rows(x), c, h, w))
+    with torch.no_grad():
+        ref = torch.nn.functional.conv3d(x, bf16_round(conv.weight), conv.bias, (1, 2, 2), (0, 1, 1))
+    oh, ow = ref.shape[-2:]
+    assert rel_err(from_rows(y, B, Fr, oh, ow), ref) < 4e-3      # same operands, fp32 accumulation, one bf16 rounding
+
+
 def test_ddpm_step_matches_reference():
     from video_diffusion_amd import GaussianDiffusion
     g = golden("p_sample_step_T250")

@@ -25,6 +25,7 @@ class TapPass(C.Structure):
         ("w_group_stride", C.c_int64),
         ("w_group_frames", C.c_int32), ("phases", C.c_int32),
         ("w_phase_stride", C.c_int64),
+        ("space_to_depth", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -63,6 +63,9 @@ struct PassDev {
     // convolution with its own weight set and output parity; blockIdx.z enumerates (frame group, phase)
     int phases;
     long long w_phase_stride;
+    // space-to-depth view of src0 (see vdmi_tap_pass): in_h / in_w are the view's extent, sh / sw the source
+    // image, csub the source's channels; chunk c reads sub-pixel c / (csub / chunk)
+    int s2d, sh, sw, csub;
 };
 
 struct KArgs {
@@ -168,7 +171,15 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
                 ok = ok && fr < g.nframes;
             }
             ok = ok && iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w;
-            ppix[u] = ok ? (fr * g.in_h + iy) * g.in_w + ix : -1;
+            if (g.s2d) {
+                // source pixel (2iy, 2ix) in the low 27 bits; bits 27..30: rows 2iy-1, 2iy and columns 2ix-1, 2ix exist
+                const int sy = 2 * iy, sx = 2 * ix;
+                const int m = (sy - 1 >= 0 && sy - 1 < g.sh ? 1 : 0) | (sy < g.sh ? 2 : 0) |
+                              (sx - 1 >= 0 && sx - 1 < g.sw ? 4 : 0) | (sx < g.sw ? 8 : 0);
+                ppix[u] = ok ? (((fr * g.sh + sy) * g.sw + sx) | (m << 27)) : 0;
+            } else {
+                ppix[u] = ok ? (fr * g.in_h + iy) * g.in_w + ix : -1;
+            }
             rx += RSTEP;
             while (rx >= g.pw) { rx -= g.pw; ++ry; }
         }
@@ -181,6 +192,19 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
             else            { src = g.src1; cs = g.c1; cbase = (c - g.nch0) * BKC; }
             const int ch = cbase + piece * 8;
             const bool chok = ch < cs;
+            if (g.s2d) {
+                const int cps = g.csub / BKC, sub = c / cps, sa = sub >> 1, sb = sub & 1;
+                const int chs = (c - sub * cps) * BKC + piece * 8;
+                const int need = ((1 << sa) | (4 << sb)) << 27, back = (1 - sa) * g.sw + (1 - sb);
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    pv[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if ((ppix[u] & need) == need)
+                        pv[u] = *reinterpret_cast<const bf16x8*>(
+                            g.src0 + (long long)((ppix[u] & 0x7ffffff) - back) * g.csub + chs);
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < LB; ++u) {
                 pv[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -629,6 +653,16 @@ int build_pass(const vdmi_tap_pass& p, int bkc, int npad, PassDev* d) {
     d->w_group_stride = p.w_group_stride;
     d->w_group_frames = p.w_group_frames > 0 ? p.w_group_frames : 1;
     d->wtile_all = (long long)npad * bkc;
+    d->s2d = 0;
+    if (p.space_to_depth) {
+        if (p.stride != 1 || p.c1 || p.c0 % 4 || (p.c0 / 4) % bkc || p.in_h < 1 || p.in_w < 1) return VDMI_E_SHAPE;
+        d->s2d = 1;
+        d->sh = p.in_h;
+        d->sw = p.in_w;
+        d->csub = p.c0 / 4;
+        d->in_h = p.in_h / 2 + 1;
+        d->in_w = p.in_w / 2 + 1;
+    }
     d->phases = p.phases > 1 ? p.phases : 1;
     d->w_phase_stride = d->phases > 1 ? p.w_phase_stride : 0;
     if (d->phases > 1 && (p.ntaps % d->phases || p.w_phase_stride % 8)) return VDMI_E_SHAPE;
@@ -722,7 +756,9 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if (A.has_res == 1 && epi != VDMI_EPI_NORM_SILU) return VDMI_E_ARG;
     if (A.main.phases > 1 && (epi != VDMI_EPI_PLAIN || A.main.phases != A.out_mul * A.out_mul)) return VDMI_E_ARG;
     // the loader indexes source pixels with 32-bit integers
-    if ((long long)A.frames * A.main.in_h * A.main.in_w > 0x7fffffffLL) return VDMI_E_SHAPE;
+    if ((long long)A.frames * A.main.in_h * A.main.in_w > (A.main.space_to_depth ? 0x7ffffffLL : 0x7fffffffLL))
+        return VDMI_E_SHAPE;
+    if (A.main.space_to_depth && (epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA)) return VDMI_E_ARG;
 
     TileCfg cands[4];
     int ncand = 0;

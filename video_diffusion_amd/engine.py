@@ -122,7 +122,8 @@ class Plan:
         bn = 64 if a.tile_bn == 64 else tile_for(a.epilogue, a.n)[0]
         in_rows = a.frames * a.main.in_h * a.main.in_w
         meta = {"kernel": f"tapgemm<epi={a.epilogue},bn={bn}>", "flops": 2.0 * m * a.n * k,
-                "bytes": 2.0 * (in_rows * (a.main.c0 + a.main.c1) + m * a.n + a.n * k)}
+                "bytes": 2.0 * (in_rows * (a.main.c0 + a.main.c1) / (4 if a.main.space_to_depth else 1)
+                                + m * a.n + a.n * k)}
         self._add(lambda s, a=a: lib.vdmi_tapgemm(C.byref(a), s), meta, name)
 
     def _base_args(self, frames, grid_h, grid_w, out, n, epilogue, out_h=None, out_w=None) -> TapGemmArgs:
@@ -304,7 +305,13 @@ class Plan:
         oh, ow = (h + 2 - 4) // 2 + 1, (w + 2 - 4) // 2 + 1
         y = self._buf(frames * oh * ow, c)
         a = self._base_args(frames, oh, ow, y, c, EPI_PLAIN)
-        _fill_pass(a.main, x, c, None, 0, h, w, 2, TAPS_4x4_S2, dn["w"].data)
+        if dn["s2d"]:
+            # 4x4 / stride 2 / pad 1 as 2x2 / stride 1 over the space-to-depth view (4*c channels)
+            _fill_pass(a.main, x, 4 * c, None, 0, h, w, 1, [(0, 0), (0, 1), (1, 0), (1, 1)], dn["w"].data)
+            a.main.space_to_depth = 1
+            a.tile_bn = dn["w"].tile_bn
+        else:
+            _fill_pass(a.main, x, c, None, 0, h, w, 2, TAPS_4x4_S2, dn["w"].data)
         a.bias = _ptr(dn["b"])
         self._tapgemm(a, name)
         return y
@@ -534,8 +541,18 @@ class UnetEngine:
         }
 
     def _pack_down(self, conv, device):
-        return {"w": PackedTaps(self._conv_w(conv.weight), conv.weight.shape[1], 0, EPI_PLAIN, device),
-                "b": conv.bias.detach().float().to(device).contiguous()}
+        bias = conv.bias.detach().float().to(device).contiguous()
+        cin = conv.weight.shape[1]
+        if cin % 64 == 0 and tuple(conv.weight.shape[2:]) == (1, 4, 4):
+            # space-to-depth form: channel (2a+b)*cin + ci, tap (dY, dX)  <-  kernel element (2dY+a, 2dX+b)
+            w = conv.weight.detach().float().cpu()[:, :, 0]                  # [n][cin][4][4]
+            subs = []
+            for a in (0, 1):
+                for b in (0, 1):
+                    subs.append(torch.stack([w[:, :, 2 * dy + a, 2 * dx + b] for dy in (0, 1) for dx in (0, 1)], dim=-1))
+            w4 = torch.cat(subs, dim=1)                                       # [n][4*cin][4]
+            return {"w": PackedTaps(w4, 4 * cin, 0, EPI_PLAIN, device, tile_bn=64), "b": bias, "s2d": True}
+        return {"w": PackedTaps(self._conv_w(conv.weight), cin, 0, EPI_PLAIN, device), "b": bias, "s2d": False}
 
     def _pack_up(self, convt, device):
         # ConvTranspose3d weight [cin][cout][1][4][4]; one 4-tap weight set per output parity (p, q)
