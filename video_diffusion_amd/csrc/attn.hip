@@ -158,42 +158,56 @@ __global__ __launch_bounds__(256) void sla_context_kernel(const __bf16* __restri
     }
     __syncthreads();
 
-    // fold into the output projection and write in vdmi_pack_taps order (1 tap, cin = heads*32).
-    // Work item = (output channel, group of 8 features d): 8 consecutive d are 8 consecutive k of one
-    // fragment, i.e. one 16-byte store.  The normalised context is re-laid as [e][d] so 8 d are two
-    // 16-byte LDS reads.
-    float* ctxT = &ctx[1][0][0];                 // [32 e][32 d], reuses the partial-sum planes
-    for (int idx = tid; idx < 32 * 32; idx += 256) {
-        const int d = idx >> 5, e = idx & 31;
-        ctxT[e * 32 + d] = ctx[0][d][e];
-    }
-    __syncthreads();
-    __bf16* wf = w_folded + (long long)frame * hid * cpad;
-    const int ksper = bkc / 16, ctn = cpad / 32;
-    for (int item = tid; item < c * 4; item += 256) {
-        const int co = item >> 2, dg = item & 3;
-        const float* wr = w_out + (long long)co * hid + hd * 32;
-        float acc[8];
+    // Fold into the output projection, W'[co][h*32+d] = sum_e Wout[co][h*32+e] * ctx[d][e], on the matrix
+    // cores and write it in vdmi_pack_taps order (1 tap, cin = heads*32).  Both factors are split into
+    // bf16 high and low parts (three products), so the fold stays within ~2^-16 of fp32 before its one
+    // rounding to bf16.  Orientation: ctx is the A operand (rows d), Wout the B operand (columns co): a
+    // lane then holds 4 consecutive d of one output channel per register quad = one 8-byte store.
+    {
+        const int l31 = lane & 31, hf = lane >> 5;
+        bf16x8 ch[2], cl[2];     // A fragments: row d = l31, k = e = 16 s + 8 hf + j
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+            for (int j = 0; j < 8; ++j) {
+                const float v = ctx[0][l31][16 * sk + 8 * hf + j];
+                const __bf16 hi = f2bf(v);
+                ch[sk][j] = hi;
+                cl[sk][j] = f2bf(v - (float)hi);
+            }
+        __bf16* wf = w_folded + (long long)frame * hid * cpad;
+        const int ksper = bkc / 16, ctn = cpad / 32;
+        for (int ct = wave; ct < c / 32; ct += 4) {
+            const int co = ct * 32 + l31;
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(ctxT + (4 * q + e) * 32 + dg * 8);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(ctxT + (4 * q + e) * 32 + dg * 8 + 4);
+            for (int sk = 0; sk < 2; ++sk) {
+                const float* wr = w_out + (long long)co * hid + hd * 32 + 16 * sk + 8 * hf;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+                bf16x8 wh, wl;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { acc[j] += wv[e] * c0[j]; acc[4 + j] += wv[e] * c1[j]; }
+                for (int j = 0; j < 8; ++j) {
+                    const float v = j < 4 ? w0[j & 3] : w1[j & 3];
+                    const __bf16 hi = f2bf(v);
+                    wh[j] = hi;
+                    wl[j] = f2bf(v - (float)hi);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[sk], wh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wh, acc, 0, 0, 0);
+            }
+            // registers 4u..4u+3 hold d = 8u + 4 hf + {0..3} of channel co
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = hd * 32 + 8 * u + 4 * hf;
+                const int chunk = k / bkc, kin = k % bkc, ks = kin >> 4, half = (kin >> 3) & 1;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[4 * u + e]);
+                *reinterpret_cast<bf16x4*>(wf + ((((long long)chunk * ctn + ct) * ksper + ks) * 64 + half * 32 + l31) * 8 +
+                                           (kin & 7)) = o;
             }
         }
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
-        const int k = hd * 32 + dg * 8;
-        const int chunk = k / bkc, kin = k % bkc, ks = kin >> 4, half = (kin >> 3) & 1;
-        const int ct = co >> 5, ln = half * 32 + (co & 31);
-        *reinterpret_cast<bf16x8*>(wf + ((((long long)chunk * ctn + ct) * ksper + ks) * 64 + ln) * 8) = o;
     }
 }
 
