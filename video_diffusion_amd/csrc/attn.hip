@@ -68,6 +68,89 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const __bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// Same attention with the keys and values of a set of token groups staged once in LDS (the gather
+// version above re-reads every k / v row n_tok times through L2).  A workgroup owns `gpb` groups
+// (spatial attention: one frame's h*w tokens; temporal: gpb neighbouring sites x F frames); set row
+// r = g * n_tok + i.  Thread = (set row, head): lanes of a wave walk consecutive rows of one head, so
+// the k / v reads of a group are LDS broadcasts.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_core_lds_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+                                                            long long rows, int heads, int n_tok, long long tok_stride,
+                                                            const float* __restrict__ bias, int gpb, long long ngroups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int hid = heads * 32, ld = 3 * hid;
+    const int krow = 2 * hid + 8;                        // padded k|v row (elements)
+    __bf16* kv = reinterpret_cast<__bf16*>(smem);         // [gpb * n_tok][krow]
+    const int tid = threadIdx.x;
+    const long long g0 = (long long)blockIdx.x * gpb;
+    const int ng = (int)min((long long)gpb, ngroups - g0);
+    const int R = ng * n_tok;
+    // group index -> first global row: groups are (outer, inner) with inner = position inside a tok_stride run
+    auto group_base = [&](long long g) -> long long {
+        const long long outer = g / tok_stride, inner = g - outer * tok_stride;
+        return outer * n_tok * tok_stride + inner;
+    };
+    const int ppr = 2 * hid / 8;                          // 16-byte pieces of a k|v row
+    for (int idx = tid; idx < R * ppr; idx += 256) {
+        const int r = idx / ppr, pc = idx - r * ppr;
+        const int g = r / n_tok, i = r - g * n_tok;
+        const long long m = group_base(g0 + g) + (long long)i * tok_stride;
+        *reinterpret_cast<bf16x8*>(kv + r * krow + pc * 8) = *reinterpret_cast<const bf16x8*>(qkv + m * ld + hid + pc * 8);
+    }
+    __syncthreads();
+    for (int p = tid; p < R * heads; p += 256) {
+        const int hd = p / R, r = p - hd * R;
+        const int g = r / n_tok, i = r - g * n_tok;
+        const long long m = group_base(g0 + g) + (long long)i * tok_stride;
+        float q[32], o[32];
+        {
+            const bf16x8* qp = reinterpret_cast<const bf16x8*>(qkv + m * ld + hd * 32);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const bf16x8 t = qp[v];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[v * 8 + e] = (float)t[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 32; ++e) o[e] = 0.f;
+        float mx = -INFINITY, l = 0.f;
+        const float* brow = bias ? bias + ((long long)hd * n_tok + i) * n_tok : nullptr;
+        const __bf16* kb = kv + (g * n_tok) * krow + hd * 32;
+        for (int j = 0; j < n_tok; ++j) {
+            const bf16x8* kp = reinterpret_cast<const bf16x8*>(kb + j * krow);
+            const bf16x8* vp = reinterpret_cast<const bf16x8*>(kb + j * krow + hid);
+            float sc = brow ? brow[j] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const bf16x8 t = kp[v];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sc += q[v * 8 + e] * (float)t[e];
+            }
+            const float mn = fmaxf(mx, sc);
+            const float corr = __expf(mx - mn), pw = __expf(sc - mn);
+            l = l * corr + pw;
+            mx = mn;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const bf16x8 t = vp[v];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[v * 8 + e] = o[v * 8 + e] * corr + pw * (float)t[e];
+            }
+        }
+        const float inv = 1.0f / l;
+        bf16x8* op = reinterpret_cast<bf16x8*>(out + m * hid + hd * 32);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = f2bf(o[v * 8 + e] * inv);
+            op[v] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // SLA context.  One workgroup per (frame, head); 4 waves split the positions.
 // ------------------------------------------------------------------------------------------
 constexpr int SLA_CH = 256;            // positions per chunk
@@ -219,6 +302,29 @@ extern "C" int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int head
     if (rows <= 0 || heads <= 0 || n_tok <= 0 || tok_stride <= 0 || rows % ((int64_t)n_tok * tok_stride))
         return VDMI_E_SHAPE;
     if (!aligned16(qkv) || !aligned16(out)) return VDMI_E_ALIGN;
+    {   // keys / values staged in LDS when a useful number of groups fits
+        const long long ngroups = rows / n_tok;
+        const size_t row_bytes = (size_t)(2 * heads * 32 + 8) * 2;
+        int gpb = (512 / heads) / n_tok;      // about two passes of the 256 threads over (row, head) pairs
+        if (gpb < 1) gpb = 1;
+        const size_t lds = (size_t)gpb * n_tok * row_bytes;
+        if (lds <= 150 * 1024) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_core_lds_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    return VDMI_E_LAUNCH;
+                attr_done = true;
+            }
+            const long long nb = (ngroups + gpb - 1) / gpb;
+            if (nb > 0x7fffffffLL) return VDMI_E_SHAPE;
+            hipLaunchKernelGGL(attn_core_lds_kernel, dim3((unsigned)nb), dim3(256), lds, static_cast<hipStream_t>(stream),
+                               static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), (long long)rows, heads, n_tok,
+                               (long long)tok_stride, bias, gpb, ngroups);
+            VDMI_LAUNCH_CHECK();
+            return VDMI_OK;
+        }
+    }
     const long long threads = (long long)rows * heads;
     const long long blocks = (threads + 255) / 256;
     if (blocks > 0x7fffffffLL) return VDMI_E_SHAPE;
