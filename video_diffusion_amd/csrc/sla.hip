@@ -204,20 +204,46 @@ __global__ __launch_bounds__(256) void sla_fold_kernel(const SlaArgs a, int c) {
     }
     __syncthreads();
     __bf16* wf = a.wf + (((long long)frame * a.heads + head) * CT) * 2 * 512;
-    // element (ct, s, lane, j) = W'[out_chan(ct, lane&31)][head*32 + slot_row(s, j, lane>>5)]; a thread writes 8 j
-    for (int idx = tid; idx < CT * 2 * 64; idx += 256) {
-        const int lane = idx & 63, s = (idx >> 6) & 1, ct = idx >> 7;
-        const float* wr = wsl + out_chan(ct, lane & 31) * 33;
-        bf16x8 o;
+    // element (ct, s, lane, j) = W'[out_chan(ct, lane&31)][head*32 + slot_row(s, j, lane>>5)].
+    // On the matrix cores: the context is the A operand (rows d), to_out the B operand (column l31 carries
+    // channel out_chan(ct, l31)); accumulator registers 8s..8s+7 of lane (l31, half) are then exactly the 8
+    // values j of fragment s.  Both factors are split into bf16 high and low parts (three products), which
+    // keeps the fold within ~2^-16 of fp32 before its single rounding to bf16.
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    bf16x8 ch[2], cl[2];
+#pragma unroll
+    for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float* cr = ctxn + slot_row(s, j, lane >> 5) * 33;
-            float acc = 0.f;
-#pragma unroll
-            for (int e = 0; e < 32; ++e) acc += wr[e] * cr[e];
-            o[j] = f2bf(acc);
+            const float v = ctxn[l31 * 33 + 16 * sk + 8 * hf + j];
+            const __bf16 hi = f2bf(v);
+            ch[sk][j] = hi;
+            cl[sk][j] = f2bf(v - (float)hi);
         }
-        *reinterpret_cast<bf16x8*>(wf + idx * 8) = o;
+    for (int ct = wave; ct < CT; ct += 4) {
+        const float* wr = wsl + out_chan(ct, l31) * 33;
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+            bf16x8 wh, wl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = wr[16 * sk + 8 * hf + j];
+                const __bf16 hi = f2bf(v);
+                wh[j] = hi;
+                wl[j] = f2bf(v - (float)hi);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[sk], wh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wh, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int sf = 0; sf < 2; ++sf) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[8 * sf + j]);
+            *reinterpret_cast<bf16x8*>(wf + ((ct * 2 + sf) * 64 + lane) * 8) = o;
+        }
     }
 }
 
