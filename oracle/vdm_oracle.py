@@ -45,6 +45,7 @@ class UnetCfg:
     use_sparse_linear_attn: bool = True
     num_buckets: int = 32          # RelativePositionBias default, vdp.py:278
     max_distance: int = 32         # instance at vdp.py:638
+    rotary: str = "half"           # "half": the reference tree's own definition; "interleaved": see rotary_interleaved
 
     @property
     def dims(self):
@@ -181,6 +182,20 @@ def rotary_half(t: Tensor, rot_dim: int) -> Tensor:
     return t * ang.cos() + torch.cat((-t2, t1), dim=-1) * ang.sin()
 
 
+def rotary_interleaved(t: Tensor, rot_dim: int) -> Tensor:
+    """The pairing of the PyPI ``rotary_embedding_torch`` library as recalled (PARITY UNPINNED: the
+    library is not installed and the reference pins no version): same frequencies as rotary_half, but
+    feature 2i rotates with feature 2i+1 instead of i with i + d/2.  t: [..., n, d], d == rot_dim."""
+    n, d = t.shape[-2], t.shape[-1]
+    assert d == rot_dim
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, rot_dim, 2).float() / rot_dim))
+    ang = torch.arange(n).float()[:, None] * inv_freq[None, :]
+    ang = ang.repeat_interleave(2, dim=-1)                       # f0 f0 f1 f1 ...
+    x1, x2 = t[..., 0::2], t[..., 1::2]
+    rot = torch.stack((-x2, x1), dim=-1).reshape(t.shape)        # (-x1, x0, -x3, x2, ...)
+    return t * ang.cos() + rot * ang.sin()
+
+
 # --------------------------------------------------------------------------
 # A6/A9  softmax attention over a token axis (vdp.py:546-612)
 # --------------------------------------------------------------------------
@@ -199,8 +214,9 @@ def attention_tokens(x: Tensor, w_qkv: Tensor, w_out: Tensor, heads: int, dim_he
     q, k, v = split(q), split(k), split(v)
     q = q * dim_head ** -0.5
     if rotary:
-        q = rotary_half(q, min(32, dim_head))
-        k = rotary_half(k, min(32, dim_head))
+        rot = rotary_interleaved if rotary == "interleaved" else rotary_half
+        q = rot(q, min(32, dim_head))
+        k = rot(k, min(32, dim_head))
     sim = q @ k.transpose(-1, -2)
     if pos_bias is not None:
         sim = sim + pos_bias
@@ -217,7 +233,7 @@ def temporal_attn_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg, pos_bias: Te
     y = layernorm_c(x, sd[p + ".fn.norm.gamma"])
     tok = y.permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
     o = attention_tokens(tok, sd[p + ".fn.fn.fn.to_qkv.weight"], sd[p + ".fn.fn.fn.to_out.weight"],
-                         cfg.attn_heads, cfg.attn_dim_head, True, pos_bias)
+                         cfg.attn_heads, cfg.attn_dim_head, cfg.rotary, pos_bias)
     o = o.reshape(b, h, w, f, c).permute(0, 4, 3, 1, 2)
     return o + x
 

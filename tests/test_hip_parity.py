@@ -225,6 +225,25 @@ def test_temporal_attention(tiny, name, key, c, div):
     assert rel_err(from_rows(y, B, Fr, h, h), ref) < LAYER_TOL
 
 
+def test_temporal_attention_interleaved_rotary():
+    """The interleaved rotary pairing (served by de-interleaving the q / k projection rows at packing time)
+    against the oracle's restatement of it, on the fused kernel."""
+    import dataclasses
+    m = make_unet(**TINY)
+    m.init_temporal_attn.fn.fn.fn.rotary_emb.convention = "interleaved"
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = golden("tiny_ops")
+    B, _, Fr, H, _ = [int(v) for v in g["shape"]]
+    L = Layers(m, B, Fr, H, H, g["t"])
+    cfg = dataclasses.replace(oracle_cfg(**TINY), rotary="interleaved")
+    x = bf16_round(inp("tiny.a32", (B, 32, Fr, H, H)))
+    y = L.run(lambda plan, P: plan._attention("init_temporal_attn", P["init_temporal_attn"], to_rows(x), 32, H, H, True))
+    ref = O.temporal_attn_residual(sd, "init_temporal_attn", x, cfg, g["relpos_bias"])
+    assert rel_err(from_rows(y, B, Fr, H, H), ref) < LAYER_TOL
+    half = O.temporal_attn_residual(sd, "init_temporal_attn", x, oracle_cfg(**TINY), g["relpos_bias"])
+    assert rel_err(ref, half) > 1e-3      # the two conventions do differ on these weights
+
+
 def test_mid_spatial_attention(tiny):
     L, sd, cfg, B, Fr, H = tiny["L"], tiny["sd"], tiny["cfg"], tiny["B"], tiny["F"], tiny["H"]
     h = H // 2

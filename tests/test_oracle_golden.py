@@ -127,3 +127,15 @@ def test_cfg3_eps_cfg():
     x, c = inp("cfg3.x", (1, 3, 16, 64, 64)), inp("cfg3.cond", (1, 768))
     out = O.unet3d_forward_cfg(m.state_dict(), oracle_cfg(**CFG3), x, g["t"], c, 2.0)
     assert rel_err(out, g["eps_cfg2"]) < TOL
+
+
+def test_rotary_interleaved_is_a_permuted_half_rotary():
+    """rot_interleaved(x) = P^-1 rot_half(P x), P = even/odd de-interleave: the identity the HIP path relies on
+    to serve the interleaved convention with the half-split kernels (the convention itself is parity unpinned)."""
+    import torch
+    from oracle import vdm_oracle as O
+    x = torch.randn(2, 3, 7, 32, generator=torch.Generator().manual_seed(5))
+    perm = torch.cat([torch.arange(0, 32, 2), torch.arange(1, 32, 2)])
+    inv = torch.argsort(perm)
+    got = O.rotary_half(x[..., perm], 32)[..., inv]
+    assert torch.allclose(got, O.rotary_interleaved(x, 32), atol=1e-6, rtol=0)

@@ -447,7 +447,9 @@ class UnetEngine:
 
     # -- parameter packing -----------------------------------------------------------------
     def _param_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.unet.parameters())
+        rot = self.unet.init_temporal_attn.fn.fn.fn.rotary_emb
+        return (str(device), getattr(rot, "convention", "half")) + \
+            tuple((p.data_ptr(), p._version) for p in self.unet.parameters())
 
     def ensure_packed(self, device):
         key = self._param_key(device)
@@ -501,6 +503,17 @@ class UnetEngine:
         wq = att.to_qkv.weight.detach().float().cpu() * gamma[None, :]        # LayerNorm gamma folded in
         hid = att.to_out.weight.shape[1]
         cdim = wq.shape[1]
+        if att.rotary_emb is not None and getattr(att.rotary_emb, "convention", "half") == "interleaved":
+            # rot_interleaved(x) = P^-1 rot_half(P x) with P the even/odd de-interleave of a head's features:
+            # apply P to the q and k rows (v and the scores are unaffected)
+            dh = att.dim_head
+            perm = torch.cat([torch.arange(0, dh, 2), torch.arange(1, dh, 2)])
+            idx = torch.arange(3 * hid)
+            for blk in (0, 1):
+                for hd in range(hid // dh):
+                    base = blk * hid + hd * dh
+                    idx[base:base + dh] = base + perm
+            wq = wq[idx]
         fused = None
         if cdim in (32, 64, 128) and att.rotary_emb is not None:
             lib = _lib.lib()

@@ -60,6 +60,11 @@ class RotaryEmbedding(_HipOnly):
         self.dim = dim
         inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
         self.register_buffer("inv_freq", inv_freq)
+        # "half": feature i pairs with i + dim/2 (the tree's definition).  "interleaved": feature 2i pairs with
+        # 2i + 1 (the PyPI library's pairing as recalled; not verifiable offline).  The scores q.k are invariant
+        # under a common permutation of the head features, so "interleaved" is served by the same kernels with
+        # the q / k projection rows de-interleaved at packing time.
+        self.convention = "half"
 
 
 class Residual(_HipOnly):
