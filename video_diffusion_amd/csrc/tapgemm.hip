@@ -324,7 +324,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
 
 template <int BM, int BN, int WM, int WN, int BKC, int EPI>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
-__attribute__((amdgpu_waves_per_eu((BM >= 256 && BM / WM >= 8) ? 4 : 2))) void tapgemm_kernel(const KArgs a) {
+__attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4 : 2))) void tapgemm_kernel(const KArgs a) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -712,16 +712,19 @@ int pick_tiles(int epi, int n, int stride, TileCfg* cands, int* ncand, int tile_
     int k = 0;
     if (epi == VDMI_EPI_NORM_SILU) {
         if (n <= 64) cands[k++] = {256, 64, 32, 64, 64};
-        else if (n <= 128) cands[k++] = {128, 128, 64, 64, 64};
+        else if (n <= 128) cands[k++] = {128, 128, 32, 64, 64};
         else if (n <= 256) cands[k++] = {64, 256, 64, 64, 64};
         else if (n <= 512) cands[k++] = {32, 512, 32, 128, 32};
         else if (n <= 1024) cands[k++] = {32, 1024, 32, 128, 32};
         else return VDMI_E_SHAPE;
     } else if (epi == VDMI_EPI_PLAIN) {
         if (n <= 64 || tile_bn == 64) { cands[k++] = {256, 64, 32, 64, 64}; cands[k++] = {64, 64, 32, 32, 64}; }
-        else { cands[k++] = {128, 128, 64, 64, 64}; cands[k++] = {64, 128, 32, 64, 64}; }
+        else {
+            cands[k++] = {128, 128, 32, 64, 64};
+            cands[k++] = {64, 128, 32, 64, 64};
+        }
     } else if (epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA) {
-        cands[k++] = {128, 128, 64, 64, 64};
+        cands[k++] = {128, 128, 32, 64, 64};
     } else {
         return VDMI_E_ARG;
     }
@@ -907,6 +910,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         VDMI_CASE(256, 64, 64, 64, 64, VDMI_EPI_NORM_SILU)
         VDMI_CASE(256, 64, 32, 64, 64, VDMI_EPI_NORM_SILU)
         VDMI_CASE(128, 128, 64, 64, 64, VDMI_EPI_NORM_SILU)
+        VDMI_CASE(128, 128, 32, 64, 64, VDMI_EPI_NORM_SILU)
         VDMI_CASE(64, 256, 64, 64, 64, VDMI_EPI_NORM_SILU)
         VDMI_CASE(32, 512, 32, 128, 32, VDMI_EPI_NORM_SILU)
         VDMI_CASE(32, 1024, 32, 128, 32, VDMI_EPI_NORM_SILU)
@@ -914,9 +918,12 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         VDMI_CASE(256, 64, 32, 64, 64, VDMI_EPI_PLAIN)
         VDMI_CASE(64, 64, 32, 32, 64, VDMI_EPI_PLAIN)
         VDMI_CASE(128, 128, 64, 64, 64, VDMI_EPI_PLAIN)
+        VDMI_CASE(128, 128, 32, 64, 64, VDMI_EPI_PLAIN)
         VDMI_CASE(64, 128, 32, 64, 64, VDMI_EPI_PLAIN)
         VDMI_CASE(128, 128, 64, 64, 64, VDMI_EPI_QKV_ATTN)
         VDMI_CASE(128, 128, 64, 64, 64, VDMI_EPI_QKV_SLA)
+        VDMI_CASE(128, 128, 32, 64, 64, VDMI_EPI_QKV_ATTN)
+        VDMI_CASE(128, 128, 32, 64, 64, VDMI_EPI_QKV_SLA)
 #undef VDMI_CASE
         return VDMI_E_ARG;
     }
