@@ -146,6 +146,17 @@ int vdmi_pack_taps(const float* w, int n, int npad, int cin0, int cin1, int ntap
 int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GroupNorm(groups, c) + SiLU of the VAE (vdp.py:93-108, 130-143) over channels-last bf16 rows
+ * [nsamples * rows_per_sample][c]: statistics per (sample, group) over the sample's rows and the
+ * group's c/groups channels (a multiple of 8), biased variance, eps inside the square root.
+ * c: 64..2048 with 256 % (c/8) == 0.  `workspace` holds vdmi_groupnorm_workspace_bytes() bytes
+ * (partial sums); x and out may alias.
+ * ------------------------------------------------------------------------------------------ */
+size_t vdmi_groupnorm_workspace_bytes(int nsamples, int64_t rows_per_sample, int c);      /* HOST */
+int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
+                        const float* gamma, const float* beta, float eps, void* workspace, vdmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Softmax attention core over a small token axis (temporal attention over frames with
  * relative-position bias, vdp.py:585-612; mid spatial attention, vdp.py:708-710).
  * qkv: bf16 [rows][3*heads*32] (q already scaled and rotated), out: bf16 [rows][heads*32].

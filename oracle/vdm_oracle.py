@@ -414,3 +414,39 @@ def p_sample_loop(sd: SD, cfg: UnetCfg, bufs: Dict[str, Tensor], x_T: Tensor, no
         eps = unet3d_forward(sd, cfg, img, t)
         img = p_sample_step(bufs, img, t, eps, noises[k])
     return img
+
+
+# --------------------------------------------------------------------------
+# N1  VAE encoder / decoder (vdp.py:83-150): (1,4,4) stride-2 convs / transposed convs,
+# GroupNorm + SiLU, 1x1 heads.  sd keys are those of the reference's VAE module.
+# --------------------------------------------------------------------------
+def _gn_silu(sd: SD, p: str, x: Tensor, groups: int) -> Tensor:
+    return F.silu(F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps=1e-5))
+
+
+def vae_decode(sd: SD, z: Tensor) -> Tensor:
+    """VAEDecoder.forward (vdp.py:122-150): z (B, latent, F, h, w) -> (B, channels, F, 8h, 8w)."""
+    d = "decoder.decoder."
+    h = F.conv3d(z, sd[d + "0.weight"], sd[d + "0.bias"])
+    h = _gn_silu(sd, d + "1", h, 32)
+    h = F.conv3d(h, sd[d + "3.weight"], sd[d + "3.bias"], padding=(0, 1, 1))
+    h = _gn_silu(sd, d + "4", h, 32)
+    h = F.conv_transpose3d(h, sd[d + "6.weight"], sd[d + "6.bias"], stride=(1, 2, 2), padding=(0, 1, 1))
+    h = _gn_silu(sd, d + "7", h, 16)
+    h = F.conv_transpose3d(h, sd[d + "9.weight"], sd[d + "9.bias"], stride=(1, 2, 2), padding=(0, 1, 1))
+    h = _gn_silu(sd, d + "10", h, 8)
+    return F.conv_transpose3d(h, sd[d + "12.weight"], sd[d + "12.bias"], stride=(1, 2, 2), padding=(0, 1, 1))
+
+
+def vae_encode(sd: SD, x: Tensor):
+    """VAEEncoder.forward (vdp.py:83-119): x (B, channels, F, H, W) -> mean, clamped logvar at (H/8, W/8)."""
+    e = "encoder.encoder."
+    h = x
+    for i, g in ((0, 8), (3, 16), (6, 32)):
+        h = F.conv3d(h, sd[e + f"{i}.weight"], sd[e + f"{i}.bias"], stride=(1, 2, 2), padding=(0, 1, 1))
+        h = _gn_silu(sd, e + f"{i + 1}", h, g)
+    h = F.conv3d(h, sd[e + "9.weight"], sd[e + "9.bias"], padding=(0, 1, 1))
+    h = _gn_silu(sd, e + "10", h, 32)
+    mean = F.conv3d(h, sd["encoder.to_mean.weight"], sd["encoder.to_mean.bias"])
+    logvar = F.conv3d(h, sd["encoder.to_logvar.weight"], sd["encoder.to_logvar.bias"]).clamp(-30.0, 20.0)
+    return mean, logvar

@@ -292,6 +292,41 @@ def test_downsample_space_to_depth(tiny, c, h, w):
     assert rel_err(from_rows(y, B, Fr, oh, ow), ref) < 4e-3      # same operands, fp32 accumulation, one bf16 rounding
 
 
+@pytest.mark.parametrize("c,groups,rows,nb", [(64, 8, 700, 3), (128, 16, 1300, 2), (256, 32, 36 * 3, 2)])
+def test_groupnorm_silu_rows(c, groups, rows, nb):
+    """vdmi_groupnorm_silu against torch.nn.functional.group_norm + SiLU on the same bf16-rounded rows."""
+    from video_diffusion_amd import _lib
+    lib = _lib.lib()
+    x = (inp(f"gn.x{c}", (nb * rows, c), scale=2.0) + 0.3).to(torch.bfloat16)
+    gamma = (1.0 + 0.3 * inp(f"gn.g{c}", (c,))).contiguous()
+    beta = (0.2 * inp(f"gn.b{c}", (c,))).contiguous()
+    xd, gd_, bd = x.to(dev()), gamma.to(dev()), beta.to(dev())
+    ws = torch.empty(lib.vdmi_groupnorm_workspace_bytes(nb, rows, c), device=dev(), dtype=torch.uint8)
+    out = torch.empty_like(xd)
+    _lib.check(lib.vdmi_groupnorm_silu(xd.data_ptr(), out.data_ptr(), nb, rows, c, groups, gd_.data_ptr(), bd.data_ptr(),
+                                       1e-5, ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    xr = x.float().reshape(nb, rows, c).permute(0, 2, 1)                   # (N, C, L)
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(xr, groups, gamma, beta, 1e-5)).permute(0, 2, 1)
+    assert rel_err(out.float().cpu().reshape(nb, rows, c), ref) < 4e-3     # fp32 math, one bf16 rounding
+
+
+def test_vae_decode_vs_reference():
+    """VAEDecoder on the HIP library against the reference VAE's own output (tests/golden/vae_tiny.npz)."""
+    from video_diffusion_amd import VAE
+    from oracle import weightgen
+    g = golden("vae_tiny")
+    vae = VAE(channels=3, latent_dim=4, base_dim=64)
+    vae.load_state_dict(weightgen.fill_state_dict(vae.state_dict(), 7))
+    vae = vae.to(dev()).eval()
+    z = inp("vae.z", tuple(int(v) for v in g["z_shape"])).to(dev())
+    with torch.no_grad():
+        y = vae.decode(z)
+    assert vae.decoder._hip_engine is not None
+    assert y.shape == g["decode"].shape
+    assert rel_err(y.cpu(), g["decode"]) < MODEL_TOL
+
+
 def test_ddpm_step_matches_reference():
     from video_diffusion_amd import GaussianDiffusion
     g = golden("p_sample_step_T250")

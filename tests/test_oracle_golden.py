@@ -139,3 +139,19 @@ def test_rotary_interleaved_is_a_permuted_half_rotary():
     inv = torch.argsort(perm)
     got = O.rotary_half(x[..., perm], 32)[..., inv]
     assert torch.allclose(got, O.rotary_interleaved(x, 32), atol=1e-6, rtol=0)
+
+
+def test_vae_oracle_matches_reference_golden():
+    """oracle.vae_decode / vae_encode against the reference VAE's outputs (oracle/make_golden_vae.py)."""
+    import torch
+    from oracle import vdm_oracle as O, weightgen
+    from tests.helpers import golden, inp, rel_err
+    from video_diffusion_amd import VAE
+    g = golden("vae_tiny")
+    sd = weightgen.fill_state_dict(VAE(channels=3, latent_dim=4, base_dim=64).state_dict(), 7)
+    z = inp("vae.z", tuple(int(v) for v in g["z_shape"]))
+    x = inp("vae.x", tuple(int(v) for v in g["x_shape"]))
+    with torch.no_grad():
+        assert rel_err(O.vae_decode(sd, z), g["decode"]) < 1e-6
+        mean, logvar = O.vae_encode(sd, x)
+        assert rel_err(mean, g["enc_mean"]) < 1e-6 and rel_err(logvar, g["enc_logvar"]) < 1e-6

@@ -96,6 +96,9 @@ _SIGNATURES = {
     "vdmi_block_scale_shift": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 +
                                [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdmi_relpos_buckets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vdmi_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
+    "vdmi_groupnorm_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "vdmi_rmsnorm_silu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                     C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_int,
                                     C.c_void_p]),

@@ -619,6 +619,113 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const __bf16* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// GroupNorm + SiLU over channels-last rows (the VAE's nn.GroupNorm(G, C) + nn.SiLU pairs,
+// vdp.py:93-108, 130-143): statistics per (sample, group) over all frames, pixels and the group's
+// channels.  Pass 1 writes per-(sample, split, 16-byte piece) partial sums, pass 2 combines them per
+// group in its prologue and normalises.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void groupnorm_partial_kernel(const __bf16* __restrict__ x, long long rows_per_sample,
+                                                                int c, float* __restrict__ part) {
+    __shared__ float sm[2][256];
+    const int ppr = c / 8, rpi = 256 / ppr;            // pieces per row, rows per iteration
+    const int tid = threadIdx.x, piece = tid % ppr, r0 = tid / ppr;
+    const int nsplit = gridDim.x, split = blockIdx.x, b = blockIdx.y;
+    const long long per = (rows_per_sample + nsplit - 1) / nsplit;
+    const long long lo = split * per, hi = lo + per < rows_per_sample ? lo + per : rows_per_sample;
+    const __bf16* xb = x + (long long)b * rows_per_sample * c;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long r = lo + r0; r < hi; r += rpi) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + r * c + piece * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
+    }
+    sm[0][tid] = s1;
+    sm[1][tid] = s2;
+    __syncthreads();
+    if (tid < ppr) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int j = tid; j < 256; j += ppr) { a1 += sm[0][j]; a2 += sm[1][j]; }
+        float* dst = part + (((long long)b * nsplit + split) * ppr + tid) * 2;
+        dst[0] = a1;
+        dst[1] = a2;
+    }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ out,
+                                                              long long rows_per_sample, int c, int groups,
+                                                              const float* __restrict__ part, int nsplit,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps) {
+    __shared__ float mean_s[256], rstd_s[256];
+    const int ppr = c / 8, rpi = 256 / ppr, ppg = ppr / groups;      // pieces per group
+    const int tid = threadIdx.x, piece = tid % ppr, r0 = tid / ppr;
+    const int b = blockIdx.y;
+    if (tid < groups) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp)
+            for (int q = 0; q < ppg; ++q) {
+                const float* src = part + (((long long)b * nsplit + sp) * ppr + tid * ppg + q) * 2;
+                a1 += src[0];
+                a2 += src[1];
+            }
+        const float cnt = (float)rows_per_sample * (float)(c / groups);
+        const float mean = a1 / cnt;
+        mean_s[tid] = mean;
+        rstd_s[tid] = rsqrtf(fmaxf(a2 / cnt - mean * mean, 0.f) + eps);
+    }
+    __syncthreads();
+    const int g = piece / ppg;
+    const float mean = mean_s[g], rstd = rstd_s[g];
+    float ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ga[e] = gamma[piece * 8 + e] * rstd;
+        be[e] = beta[piece * 8 + e] - mean * ga[e];
+    }
+    const long long per = (rows_per_sample + gridDim.x - 1) / gridDim.x;
+    const long long lo = blockIdx.x * per, hi = lo + per < rows_per_sample ? lo + per : rows_per_sample;
+    const long long base = (long long)b * rows_per_sample * c;
+    for (long long r = lo + r0; r < hi; r += rpi) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + base + r * c + piece * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(fmaf((float)v[e], ga[e], be[e])));
+        *reinterpret_cast<bf16x8*>(out + base + r * c + piece * 8) = o;
+    }
+}
+
+static int groupnorm_splits(int64_t rows_per_sample) {
+    int64_t n = rows_per_sample / 512;
+    return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+}
+
+extern "C" size_t vdmi_groupnorm_workspace_bytes(int nsamples, int64_t rows_per_sample, int c) {
+    if (nsamples <= 0 || rows_per_sample <= 0 || c <= 0) return 0;
+    return (size_t)nsamples * groupnorm_splits(rows_per_sample) * (c / 8) * 2 * sizeof(float);
+}
+
+extern "C" int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
+                                   const float* gamma, const float* beta, float eps, void* workspace,
+                                   vdmi_stream stream_) {
+    if (!x || !out || !gamma || !beta || !workspace) return VDMI_E_ARG;
+    if (nsamples <= 0 || nsamples > 65535 || rows_per_sample <= 0 || c < 64 || c > 2048 || 256 % (c / 8) || c % 8 ||
+        groups <= 0 || groups > 256 || c % groups || (c / groups) % 8)
+        return VDMI_E_SHAPE;
+    if (!aligned16(x) || !aligned16(out)) return VDMI_E_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int nsplit = groupnorm_splits(rows_per_sample);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(groupnorm_partial_kernel, dim3((unsigned)nsplit, (unsigned)nsamples), dim3(256), 0, stream,
+                       static_cast<const __bf16*>(x), (long long)rows_per_sample, c, part);
+    VDMI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)nsplit, (unsigned)nsamples), dim3(256), 0, stream,
+                       static_cast<const __bf16*>(x), static_cast<__bf16*>(out), (long long)rows_per_sample, c, groups,
+                       part, nsplit, gamma, beta, eps);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
 extern "C" int vdmi_rmsnorm_silu(const void* x, int ldx, void* out, int ldo, int64_t rows, int c, const float* gain,
                                  int64_t gain_bstride, const float* shift, int64_t shift_bstride,
                                  int64_t rows_per_batch, float norm_scale, const void* res, int ld_res,

@@ -1,7 +1,7 @@
 """VAE and FrameConditioningEncoder with the reference's layers and state-dict keys
 (vdp.py:83-269 of the reference).  They sit outside p_sample_loop (the VAE decodes once after the
-loop, the frame encoder feeds the cross-attention path) and are plain torch modules for now; the
-HIP work covers the denoiser and the posterior step.
+loop, the frame encoder feeds the cross-attention path).  The decoder runs on the HIP library for GPU
+tensors under no_grad (vae_engine.py); the encoder and the frame encoder are plain torch modules.
 """
 import torch
 from torch import nn
@@ -38,6 +38,13 @@ class VAEDecoder(nn.Module):
         )
 
     def forward(self, z):
+        # GPU tensors outside autograd: the HIP launch plan (vae_engine.py); it raises if libvdmi.so is missing.
+        # CPU tensors and training keep the torch layers the parameters live in.
+        if z.is_cuda and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            if getattr(self, "_hip_engine", None) is None:
+                from .vae_engine import VaeDecodeEngine
+                object.__setattr__(self, "_hip_engine", VaeDecodeEngine(self))
+            return self._hip_engine.decode(z)
         return self.decoder(z)
 
 
