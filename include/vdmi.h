@@ -129,6 +129,8 @@ typedef struct vdmi_tapgemm_args {
     int32_t sla_hw;
     int32_t tile_bn;               /* PLAIN only: 0 = automatic, 64 = force 64-channel output tiles
                                       (more pixels per workgroup, less weight traffic)        */
+    int32_t q_cols;                /* QKV_ATTN: leading output columns that are queries (scaled by
+                                      q_scale); 0 = n/3 (q, k, v thirds), n = a query-only projection */
 } vdmi_tapgemm_args;
 
 /* HOST. Tile the library will use for (epilogue, n): *bn = output-channel tile, *bkc = input
@@ -144,6 +146,30 @@ int vdmi_pack_taps(const float* w, int n, int npad, int cin0, int cin1, int ntap
                    uint16_t* out, float* colsum);
 
 int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cross-attention to previous-frame features: CrossAttention (vdp.py:480-528) inside
+ * Residual(PreNorm(.)) at vdp.py:803-805 and :824-826, heads of 32 features.
+ *
+ * Keys/values depend only on the context.  vdmi_xattn_context turns the fp32 context
+ * [b][l][d] into bf16 rows [b*l][d], multiplied per sample by keep[b] (1 - the null-conditioning mask
+ * of vdp.py:782-789; NULL = all ones).  The caller projects those rows with vdmi_tapgemm onto
+ * [b*l][ldkv] (per layer: heads*32 key columns, then heads*32 value columns) and vdmi_xattn_pack_kv
+ * reorders them into MFMA operand fragments, vdmi_xattn_kv_elems() bf16 elements in total, layer
+ * `i` starting at element i * vdmi_xattn_kv_elems(1, b, l, heads).
+ *
+ * vdmi_xattn_core: q bf16 [b*rows_per_sample][ldq] (already LayerNormed, projected and multiplied by
+ * dim_head^-0.5 * log2(e): vdmi_tapgemm with the QKV_ATTN epilogue and q_cols = n) -> o bf16
+ * [b*rows_per_sample][heads*32] = softmax(q k^T) v per head.  Within a head's 32 output columns the
+ * feature order is permuted: column 16*h + r holds feature (r&3) + 8*(r>>2) + 4*h  (h = 0,1; r = 0..15);
+ * the out-projection weights must be packed with their input columns in the same order.
+ * ------------------------------------------------------------------------------------------ */
+size_t vdmi_xattn_kv_elems(int nlayers, int b, int l, int heads);                              /* HOST */
+int vdmi_xattn_context(const float* ctx, const float* keep, void* rows, int b, int l, int d, vdmi_stream stream);
+int vdmi_xattn_pack_kv(const void* kvrows, int ldkv, void* kvpack, int nlayers, int b, int l, int heads,
+                       vdmi_stream stream);
+int vdmi_xattn_core(const void* q, int ldq, void* o, const void* kvpack_layer, int b, int64_t rows_per_sample,
+                    int l, int heads, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(groups, c) + SiLU of the VAE (vdp.py:93-108, 130-143) over channels-last bf16 rows

@@ -268,6 +268,40 @@ def sla_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg) -> Tensor:
 
 
 # --------------------------------------------------------------------------
+# N2  cross-attention to previous-frame features (vdp.py:480-528, wiring :664-682, :803-805, :824-826)
+# --------------------------------------------------------------------------
+def cross_attn_residual(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int, dim_head: int) -> Tensor:
+    """Residual(PreNorm(CrossAttention)): queries are all f*h*w positions of a sample, keys/values the
+    sample's context tokens ctx [B, L, context_dim]; plain softmax, to_out has a bias."""
+    b, c, f, h, w = x.shape
+    y = layernorm_c(x, sd[p + ".fn.norm.gamma"])
+    tok = y.permute(0, 2, 3, 4, 1).reshape(b, f * h * w, c)
+    q = F.linear(tok, sd[p + ".fn.fn.to_q.weight"])
+    k = F.linear(ctx, sd[p + ".fn.fn.to_k.weight"])
+    v = F.linear(ctx, sd[p + ".fn.fn.to_v.weight"])
+
+    def split(t):
+        return t.reshape(b, t.shape[1], heads, dim_head).transpose(1, 2)      # [b, heads, n, d]
+
+    q, k, v = split(q), split(k), split(v)
+    attn = ((q @ k.transpose(-1, -2)) * dim_head ** -0.5).softmax(dim=-1)
+    out = (attn @ v).transpose(1, 2).reshape(b, f * h * w, heads * dim_head)
+    out = F.linear(out, sd[p + ".fn.fn.to_out.weight"], sd[p + ".fn.fn.to_out.bias"])
+    return out.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3) + x
+
+
+def frame_encoder(sd: SD, prev_latents: Tensor) -> Tensor:
+    """FrameConditioningEncoder.forward (vdp.py:239-269): three (1,3,3) convs (strides 1, 2, 2) with SiLU,
+    then 'b c f h w -> b (f h w) c'.  sd keys are those of the module ('feature_extractor.N.*')."""
+    h = prev_latents
+    for i, stride in ((0, 1), (2, 2), (4, 2)):
+        h = F.silu(F.conv3d(h, sd[f"feature_extractor.{i}.weight"], sd[f"feature_extractor.{i}.bias"],
+                            stride=(1, stride, stride), padding=(0, 1, 1)))
+    b, c, f, hh, ww = h.shape
+    return h.permute(0, 2, 3, 4, 1).reshape(b, f * hh * ww, c)
+
+
+# --------------------------------------------------------------------------
 # A8  resamplers (vdp.py:374-378)
 # --------------------------------------------------------------------------
 def downsample(sd: SD, p: str, x: Tensor) -> Tensor:
@@ -284,12 +318,17 @@ def upsample(sd: SD, p: str, x: Tensor) -> Tensor:
 # Unet3D.forward on the sampling path (vdp.py:756-831)
 # --------------------------------------------------------------------------
 def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
-                   cond: Optional[Tensor] = None, null_cond: bool = False) -> Tensor:
-    """frame_cond_features=None, focus_present_mask all-False (what p_sample passes, vdp.py:978-983).
+                   cond: Optional[Tensor] = None, null_cond: bool = False,
+                   frame_cond: Optional[Tensor] = None, frame_keep: Optional[Tensor] = None) -> Tensor:
+    """focus_present_mask all-False (what p_sample passes, vdp.py:978-983).
 
     ``null_cond`` selects null_cond_prob = 1 (True) or 0 (False) — the two values
-    forward_with_cond_scale uses (vdp.py:739,747).
+    forward_with_cond_scale uses (vdp.py:739,747).  ``frame_cond`` [B, L, frame_cond_dim] switches on the
+    cross-attention layers (vdp.py:803-805, 824-826); ``frame_keep`` [B] of 0/1 is one minus the
+    null-conditioning mask of vdp.py:782-789 (the random draw is the caller's).
     """
+    if frame_cond is not None and frame_keep is not None:
+        frame_cond = frame_cond * frame_keep.to(frame_cond.dtype)[:, None, None]
     nf = x.shape[2]
     bias = relpos_bias(sd["time_rel_pos_bias.relative_attention_bias.weight"], nf,
                        cfg.num_buckets, cfg.max_distance)
@@ -312,6 +351,8 @@ def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
         if cfg.use_sparse_linear_attn:
             x = sla_residual(sd, p + ".2", x, cfg)
         x = temporal_attn_residual(sd, p + ".3", x, cfg, bias)
+        if frame_cond is not None:
+            x = cross_attn_residual(sd, f"frame_cross_attns_down.{i}", x, frame_cond, cfg.attn_heads, cfg.attn_dim_head)
         skips.append(x)
         if i < nres - 1:
             x = downsample(sd, p + ".4", x)
@@ -329,6 +370,8 @@ def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
         if cfg.use_sparse_linear_attn:
             x = sla_residual(sd, p + ".2", x, cfg)
         x = temporal_attn_residual(sd, p + ".3", x, cfg, bias)
+        if frame_cond is not None:
+            x = cross_attn_residual(sd, f"frame_cross_attns_up.{i}", x, frame_cond, cfg.attn_heads, cfg.attn_dim_head)
         if i < nres - 1:
             x = upsample(sd, p + ".4", x)
 
@@ -397,6 +440,19 @@ def p_sample_step(bufs: Dict[str, Tensor], x: Tensor, t: Tensor, eps: Tensor, z:
     logvar = _bcast(bufs["posterior_log_variance_clipped"], t, x)
     nonzero = (1 - (t == 0).float()).reshape(x.shape[0], *((1,) * (x.dim() - 1)))
     return mean + nonzero * (0.5 * logvar).exp() * z
+
+
+def frame_cfg_step(sd: SD, cfg: UnetCfg, bufs: Dict[str, Tensor], x: Tensor, t: Tensor, frame_cond: Tensor,
+                   scale: float, z: Tensor) -> Tensor:
+    """One step of the frame-conditioned loop in GaussianDiffusion.sample (vdp.py:1055-1080): two
+    evaluations (conditioning kept / zeroed), guidance, clamp, posterior; the noise draw z is used for
+    i > 0 and replaced by zeros at i == 0, which p_sample_step's nonzero mask reproduces."""
+    if scale == 1.0:
+        return p_sample_step(bufs, x, t, unet3d_forward(sd, cfg, x, t, frame_cond=frame_cond), z)
+    ones = torch.ones(x.shape[0])
+    e_c = unet3d_forward(sd, cfg, x, t, frame_cond=frame_cond, frame_keep=ones)
+    e_u = unet3d_forward(sd, cfg, x, t, frame_cond=frame_cond, frame_keep=0 * ones)
+    return p_sample_step(bufs, x, t, e_u + scale * (e_c - e_u), z)
 
 
 def p_sample_loop(sd: SD, cfg: UnetCfg, bufs: Dict[str, Tensor], x_T: Tensor, noises: Sequence[Tensor],

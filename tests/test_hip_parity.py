@@ -292,6 +292,77 @@ def test_downsample_space_to_depth(tiny, c, h, w):
     assert rel_err(from_rows(y, B, Fr, oh, ow), ref) < 4e-3      # same operands, fp32 accumulation, one bf16 rounding
 
 
+@pytest.mark.parametrize("L,rps,nb,heads", [(1, 40, 2, 8), (18, 576, 2, 8), (32, 100, 3, 4), (50, 33, 2, 8), (131, 257, 2, 2)])
+def test_xattn_core_vs_torch(L, rps, nb, heads):
+    """vdmi_xattn_pack_kv + vdmi_xattn_core against softmax(q k^T) v in fp32 on the same bf16 inputs."""
+    import math
+    from video_diffusion_amd import _lib
+    lib = _lib.lib()
+    hid, nl = heads * 32, 2
+    q = (0.5 * inp(f"xa.q{L}", (nb * rps, hid))).to(torch.bfloat16)
+    kv = (1.5 * inp(f"xa.kv{L}", (nb * L, nl * 2 * hid))).to(torch.bfloat16)
+    qd, kvd = q.to(dev()), kv.to(dev())
+    per = lib.vdmi_xattn_kv_elems(1, nb, L, heads)
+    assert lib.vdmi_xattn_kv_elems(nl, nb, L, heads) == nl * per
+    pack = torch.empty(nl * per, device=dev(), dtype=torch.bfloat16)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.vdmi_xattn_pack_kv(kvd.data_ptr(), nl * 2 * hid, pack.data_ptr(), nl, nb, L, heads, s))
+    perm = torch.tensor([32 * hd + (r & 3) + 8 * (r >> 2) + 4 * hh for hd in range(heads) for hh in (0, 1) for r in range(16)])
+    for layer in range(nl):
+        o = torch.empty(nb * rps, hid, device=dev(), dtype=torch.bfloat16)
+        _lib.check(lib.vdmi_xattn_core(qd.data_ptr(), hid, o.data_ptr(), pack.data_ptr() + layer * per * 2, nb, rps, L, heads, s))
+        torch.cuda.synchronize()
+        qf = q.float().reshape(nb, rps, heads, 32).transpose(1, 2)
+        kf = kv.float()[:, layer * 2 * hid:layer * 2 * hid + hid].reshape(nb, L, heads, 32).transpose(1, 2)
+        vf = kv.float()[:, layer * 2 * hid + hid:(layer + 1) * 2 * hid].reshape(nb, L, heads, 32).transpose(1, 2)
+        attn = (qf @ kf.transpose(-1, -2) * math.log(2.0)).softmax(dim=-1)       # the kernel works in the log2 domain
+        ref = (attn @ vf).transpose(1, 2).reshape(nb * rps, hid)
+        assert rel_err(o.float().cpu(), ref[:, perm]) < 8e-3
+
+
+def test_unet_frame_conditioning_vs_reference():
+    """Unet3D with frame_cond_features (cross-attention layers on) against the reference's outputs."""
+    g = golden("tiny_framecond")
+    m = make_unet(**TINY).to(dev())
+    x = inp("fc.x", tuple(int(v) for v in g["x_shape"])).to(dev())
+    t, f = g["t"].to(dev()), g["features"].to(dev())
+    with torch.no_grad():
+        assert rel_err(m(x, t, frame_cond_features=f).cpu(), g["eps_cond"]) < MODEL_TOL
+        assert rel_err(m(x, t, frame_cond_features=f, null_frame_cond_prob=1.).cpu(), g["eps_null"]) < MODEL_TOL
+        mixed = f * g["keep_mixed"].to(dev())[:, None, None]
+        assert rel_err(m(x, t, frame_cond_features=mixed).cpu(), g["eps_mixed"]) < MODEL_TOL
+        assert rel_err(m(x, t).cpu(), g["eps_plain"]) < MODEL_TOL           # the plan without the layers still works
+        # the conditioning must matter at this tolerance, or the test could not see a wrong layer
+        assert rel_err(g["eps_cond"], g["eps_plain"]) > 5 * MODEL_TOL
+
+
+@pytest.mark.parametrize("scale", [1.0, 1.5])
+def test_frame_cond_sample_loop_vs_oracle(scale):
+    """The frame-conditioned loop of sample() (doubled-batch guidance, cached keys/values) against the oracle's
+    restatement of vdp.py:1046-1080 with the same start and noise draws."""
+    from video_diffusion_amd import GaussianDiffusion
+    g = golden("tiny_framecond")
+    T, steps = 250, 3                  # early steps of a long schedule: free running stays well conditioned
+    m = make_unet(**TINY)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    gd = GaussianDiffusion(m, torch.nn.Identity(), image_size=96, num_frames=4, channels=3, timesteps=T).to(dev())
+    shape = tuple(int(v) for v in g["x_shape"])
+    x_T = inp("fc.xT", shape)
+    noises = [inp(f"fc.z{k}", shape) for k in range(steps)]
+    out = gd.frame_cond_sample_loop(shape, g["features"].to(dev()), scale, x_T=x_T.to(dev()),
+                                    noises=[z.to(dev()) for z in noises], steps=steps)
+    cfg, bufs = oracle_cfg(**TINY), O.diffusion_buffers(T)
+    img = x_T
+    with torch.no_grad():
+        for k, i in enumerate(list(reversed(range(T)))[:steps]):
+            img = O.frame_cfg_step(sd, cfg, bufs, img, torch.full((shape[0],), i, dtype=torch.long), g["features"], scale, noises[k])
+    assert rel_err(out.cpu(), img) < 5e-2
+    # graph replay path: same shapes, internal noise; must run and stay finite
+    gd.noise_source = "philox"
+    y = gd.frame_cond_sample_loop(shape, g["features"].to(dev()), scale, steps=5)
+    assert torch.isfinite(y).all() and y.shape == shape
+
+
 @pytest.mark.parametrize("c,groups,rows,nb", [(64, 8, 700, 3), (128, 16, 1300, 2), (256, 32, 36 * 3, 2)])
 def test_groupnorm_silu_rows(c, groups, rows, nb):
     """vdmi_groupnorm_silu against torch.nn.functional.group_norm + SiLU on the same bf16-rounded rows."""

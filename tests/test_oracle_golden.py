@@ -155,3 +155,25 @@ def test_vae_oracle_matches_reference_golden():
         assert rel_err(O.vae_decode(sd, z), g["decode"]) < 1e-6
         mean, logvar = O.vae_encode(sd, x)
         assert rel_err(mean, g["enc_mean"]) < 1e-6 and rel_err(logvar, g["enc_logvar"]) < 1e-6
+
+
+def test_frame_conditioning_oracle_matches_reference_golden():
+    """oracle.frame_encoder and unet3d_forward(frame_cond=...) against the reference's FrameConditioningEncoder and
+    Unet3D outputs (oracle/make_golden_framecond.py): conditioning kept, zeroed, zeroed for one sample."""
+    import torch
+    from oracle import vdm_oracle as O, weightgen
+    from tests.helpers import TINY, golden, inp, oracle_cfg, rel_err
+    from video_diffusion_amd import Unet3D
+    from video_diffusion_amd.vae import FrameConditioningEncoder
+    g = golden("tiny_framecond")
+    sd = weightgen.fill_state_dict(Unet3D(**TINY).state_dict(), 0)
+    esd = weightgen.fill_state_dict(FrameConditioningEncoder(3, 512, 2).state_dict(), 11)
+    cfg = oracle_cfg(**TINY)
+    x = inp("fc.x", tuple(int(v) for v in g["x_shape"]))
+    prev = inp("fc.prev", tuple(int(v) for v in g["prev_shape"]))
+    with torch.no_grad():
+        f = O.frame_encoder(esd, prev)
+        assert rel_err(f, g["features"]) < 1e-6
+        assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], frame_cond=f), g["eps_cond"]) < 1e-5
+        assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], frame_cond=f, frame_keep=torch.zeros(2)), g["eps_null"]) < 1e-5
+        assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], frame_cond=f, frame_keep=g["keep_mixed"]), g["eps_mixed"]) < 1e-5

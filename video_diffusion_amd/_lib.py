@@ -51,6 +51,7 @@ class TapGemmArgs(C.Structure):
         ("rot_frames", C.c_int32), ("rot_hw", C.c_int32),
         ("out2", C.c_void_p),
         ("sla_hw", C.c_int32), ("tile_bn", C.c_int32),
+        ("q_cols", C.c_int32),
     ]
 
 
@@ -99,6 +100,11 @@ _SIGNATURES = {
     "vdmi_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
     "vdmi_groupnorm_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "vdmi_xattn_kv_elems": (C.c_size_t, [C.c_int] * 4),
+    "vdmi_xattn_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vdmi_xattn_pack_kv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vdmi_xattn_core": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                  C.c_void_p]),
     "vdmi_rmsnorm_silu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                     C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_int,
                                     C.c_void_p]),

@@ -755,6 +755,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if (epi == VDMI_EPI_NORM_SILU && !A.gain) return VDMI_E_ARG;
     if ((epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA) && !A.colsum) return VDMI_E_ARG;
     if (epi == VDMI_EPI_QKV_SLA && (!A.out2 || A.sla_hw <= 0)) return VDMI_E_ARG;
+    if (A.q_cols < 0 || A.q_cols % 32 || (A.q_cols && epi != VDMI_EPI_QKV_ATTN)) return VDMI_E_ARG;
     if (A.has_res == 2 && (!A.res_identity || A.ld_res % 8 || !aligned16(A.res_identity))) return VDMI_E_ARG;
     if (A.has_res == 1 && epi != VDMI_EPI_NORM_SILU) return VDMI_E_ARG;
     if (A.main.phases > 1 && (epi != VDMI_EPI_PLAIN || A.main.phases != A.out_mul * A.out_mul)) return VDMI_E_ARG;
@@ -892,11 +893,11 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         k.rot_hw = A.rot_hw > 0 ? A.rot_hw : 1;
         k.out2 = static_cast<__bf16*>(A.out2);
         k.sla_hw = A.sla_hw > 0 ? A.sla_hw : 1;
-        k.heads32 = A.n / 3;
+        k.heads32 = (epi == VDMI_EPI_QKV_ATTN && A.q_cols > 0) ? A.q_cols : A.n / 3;
 #ifdef VDMI_DIAG_STAMPS
         if (const char* dp = std::getenv("VDMI_DIAG_PTR")) k.diag = reinterpret_cast<unsigned long long*>(std::strtoull(dp, nullptr, 0));
 #endif
-        if (is_qkv && (A.n % 96)) return VDMI_E_SHAPE;
+        if (is_qkv && (k.heads32 % 32 || A.n % k.heads32)) return VDMI_E_SHAPE;
 
         frames *= k.main.phases;    // grid.z: (frame group, phase)
         if (best_tiles > 0x7fffffffLL || frames > 65535) return VDMI_E_SHAPE;

@@ -230,14 +230,112 @@ class GaussianDiffusion(nn.Module):
         return img
 
     @torch.inference_mode()
+    def frame_cond_sample_loop(self, shape, frame_cond_features, frame_cond_scale=1.0, x_T=None, noises=None,
+                               steps=None):
+        """The denoising loop of sample() with previous-frame conditioning (reference vdp.py:1046-1080): with
+        frame_cond_scale != 1 every step evaluates the denoiser with the conditioning kept and with it zeroed
+        and extrapolates between the two; the step itself is the static-clip posterior step.
+
+        With the HIP Unet3D the two evaluations run as ONE pass over a doubled batch (samples are
+        independent, so the results are those of two passes), the keys/values of the context are
+        projected once for the whole loop, and each step replays one captured HIP graph.
+        x_T / noises (one tensor per step, in execution order) may be injected for parity checks; `steps`
+        stops after that many steps (parity checks and benchmarks)."""
+        from .modules import Unet3D
+        device = self.betas.device
+        fn = self.denoise_fn
+        B = shape[0]
+        feats = frame_cond_features.to(device=device, dtype=torch.float32)
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
+        guided = frame_cond_scale != 1.0
+        order = list(reversed(range(0, self.num_timesteps)))[:steps]
+
+        if not (isinstance(fn, Unet3D) and fn.has_frame_cross_attn and not fn.has_cond and not self.use_dynamic_thres):
+            # any other denoiser: the reference's loop, call for call
+            for k, i in enumerate(order):
+                t = torch.full((B,), i, device=device, dtype=torch.long)
+                nz = None if noises is None else noises[k].to(device)
+                if guided:
+                    e_c = fn(img, t, frame_cond_features=feats, null_frame_cond_prob=0.)
+                    e_u = fn(img, t, frame_cond_features=feats, null_frame_cond_prob=1.)
+                    nz = torch.randn_like(img) if nz is None else nz
+                    img = self.ddpm_step(img, e_u + frame_cond_scale * (e_c - e_u), t, noise=nz, clip_denoised=True)
+                else:
+                    img = self.p_sample(img, t, frame_cond_features=feats, noise=nz)
+            return img
+
+        rep = 2 if guided else 1
+        _, Cc, Fr, H, W = shape
+        eng = fn.engine()
+        plan = eng.plan(rep * B, Fr, H, W, device, feats.shape[1])
+        plan.ctx_in.copy_(feats.repeat(rep, 1, 1))
+        plan.ctx_keep.fill_(1)
+        if guided:
+            plan.ctx_keep[B:].fill_(0)
+        plan.run_context()
+        state = img.contiguous().clone()
+        eps = torch.empty(shape, device=device, dtype=torch.float32)
+        t_b = plan.t_in[:B]
+        z = torch.zeros(shape, device=device, dtype=torch.float32) if self.noise_source == "torch" else None
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+        def step(noise):
+            plan.x_in[:B].copy_(state)
+            if guided:
+                plan.x_in[B:].copy_(state)
+            plan.run()
+            if guided:
+                e_c, e_u = plan.eps_out[:B], plan.eps_out[B:]
+                torch.add(e_u, e_c - e_u, alpha=frame_cond_scale, out=eps)
+            else:
+                eps.copy_(plan.eps_out)
+            self.ddpm_step(state, eps, t_b, noise=noise, clip_denoised=True, out=state, seed=seed)
+
+        def drawn_step():
+            if z is not None:
+                z.normal_()
+            step(z)
+
+        graph = None
+        if noises is None and self.use_hip_graph:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                saved = state.clone()
+                plan.t_in.fill_(order[0])
+                drawn_step()                # warm-up outside capture
+                state.copy_(saved)
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                drawn_step()
+            state.copy_(saved)
+        for k, i in enumerate(order):
+            plan.t_in.fill_(i)
+            if graph is not None:
+                graph.replay()
+            elif noises is not None:
+                step(noises[k].to(device=device, dtype=torch.float32).contiguous())
+            else:
+                drawn_step()
+        return state.clone()
+
+    @torch.inference_mode()
     def sample(self, batch_size=16, prev_frames=None, frame_cond_scale=1.0):
         # reference: vdp.py:1016-1089 (latent-space sampling + VAE decode)
         device = next(self.denoise_fn.parameters()).device
         latent_size = self.image_size // 8
         latent_channels = self.vae.latent_dim
+        shape = (batch_size, latent_channels, self.num_frames, latent_size, latent_size)
         if exists(prev_frames) and exists(self.frame_cond_encoder):
-            raise NotImplementedError("frame-conditioned sampling (cross-attention to previous frames) is not built yet")
-        img = self.p_sample_loop((batch_size, latent_channels, self.num_frames, latent_size, latent_size))
+            self.vae.eval()
+            prev_normalized = (prev_frames * 2.0 - 1.0).clamp(-1, 1)
+            prev_latents, _ = self.vae.encode(prev_normalized)
+            frame_cond_features = self.frame_cond_encoder(prev_latents * self.latent_scale)
+            img = self.frame_cond_sample_loop(shape, frame_cond_features, frame_cond_scale)
+        else:
+            img = self.p_sample_loop(shape)
         self.vae.eval()
         samples = self.vae.decode(img / self.latent_scale)
         samples = samples.clamp(-1, 1)
@@ -256,11 +354,14 @@ class GaussianDiffusion(nn.Module):
         with torch.no_grad():
             x_start_latent, _ = self.vae.encode(x_start_normalized)
         x_start_latent = (x_start_latent * self.latent_scale).clamp(-10, 10)
+        frame_cond_features = None
         if exists(prev_frames) and exists(self.frame_cond_encoder):
-            raise NotImplementedError("frame conditioning is not built yet")
+            with torch.no_grad():
+                prev_latents, _ = self.vae.encode((prev_frames * 2.0 - 1.0).clamp(-1, 1))
+            frame_cond_features = self.frame_cond_encoder(prev_latents * self.latent_scale)
         noise = default(noise, lambda: torch.randn_like(x_start_latent))
         x_noisy = self.q_sample(x_start=x_start_latent, t=t, noise=noise)
-        predicted_noise = self.denoise_fn(x_noisy, t, frame_cond_features=None,
+        predicted_noise = self.denoise_fn(x_noisy, t, frame_cond_features=frame_cond_features,
                                           null_frame_cond_prob=null_frame_cond_prob,
                                           prob_focus_present=prob_focus_present,
                                           focus_present_mask=focus_present_mask)

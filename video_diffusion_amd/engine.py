@@ -89,9 +89,11 @@ class _Call:
 class Plan:
     """All launches of one Unet3D forward for a fixed (B, F, H, W)."""
 
-    def __init__(self, eng: "UnetEngine", B: int, F: int, H: int, W: int, device, build: bool = True):
+    def __init__(self, eng: "UnetEngine", B: int, F: int, H: int, W: int, device, build: bool = True, L: int = 0):
         self.eng, self.B, self.F, self.H, self.W, self.device = eng, B, F, H, W, device
+        self.L = L                            # context tokens per sample of the frame cross-attention (0: layers skipped)
         self.calls: List[_Call] = []
+        self.ctx_calls: List[_Call] = []      # key/value projection of the context: once per context, not per step
         self.keep: List[object] = []          # tensors / ctypes objects the calls point into
         u = eng.unet
         self.x_in = torch.zeros(B, u.channels, F, H, W, device=device, dtype=torch.float32)
@@ -300,6 +302,56 @@ class Plan:
         self._tapgemm(b, name + ".out")
         return y
 
+    def _setup_context(self):
+        """Buffers and launches that turn the context [B][L][D] into the packed keys/values of every
+        cross-attention layer (reference vdp.py:511-513: to_k / to_v act on the context only)."""
+        lib = _lib.lib()
+        X = self.eng.packed["xattn"]
+        B, L, D, dev = self.B, self.L, X["ctx_dim"], self.device
+        nl, hid = X["nl"], X["hid"]
+        self.ctx_in = torch.zeros(B, L, D, device=dev, dtype=torch.float32)
+        self.ctx_keep = torch.ones(B, device=dev, dtype=torch.float32)
+        ctx_rows = self._buf(B * L, D)
+        kv_rows = self._buf(B * L, nl * 2 * hid)
+        self.kv_layer_elems = lib.vdmi_xattn_kv_elems(1, B, L, hid // 32)
+        self.kv_pack = torch.empty(nl * self.kv_layer_elems, device=dev, dtype=torch.bfloat16)
+        calls, self.calls = self.calls, self.ctx_calls
+        self._add(lambda s: lib.vdmi_xattn_context(self.ctx_in.data_ptr(), self.ctx_keep.data_ptr(), ctx_rows.data_ptr(),
+                                                   B, L, D, s), None, "xattn.context")
+        a = self._base_args(1, 1, B * L, kv_rows, nl * 2 * hid, EPI_PLAIN)
+        _fill_pass(a.main, ctx_rows, D, None, 0, 1, B * L, 1, [(0, 0)], X["wkv"].data)
+        self._tapgemm(a, "xattn.kv")
+        self._add(lambda s: lib.vdmi_xattn_pack_kv(kv_rows.data_ptr(), nl * 2 * hid, self.kv_pack.data_ptr(), nl, B, L,
+                                                   hid // 32, s), None, "xattn.pack_kv")
+        self.calls = calls
+
+    def _cross_attention(self, name, idx, x, c, h, w) -> torch.Tensor:
+        """Residual(PreNorm(CrossAttention)) to the context (reference vdp.py:480-528, 803-805, 824-826)."""
+        lib = _lib.lib()
+        X = self.eng.packed["xattn"]
+        xa, hid = X["layers"][idx], X["hid"]
+        frames, hw = self.B * self.F, h * w
+        rows = frames * hw
+        q = self._buf(rows, hid)
+        a = self._base_args(frames, h, w, q, hid, EPI_QKV_ATTN)
+        _fill_pass(a.main, x, c, None, 0, h, w, 1, [(0, 0)], xa["wq"].data)
+        a.colsum = _ptr(xa["wq"].colsum)
+        a.ln_eps, a.q_scale, a.q_cols = 1e-5, X["scale"] * math.log2(math.e), hid
+        self._tapgemm(a, name + ".q")
+        o = self._buf(rows, hid)
+        kvp = self.kv_pack.data_ptr() + idx * self.kv_layer_elems * 2
+        nt = (self.L + 31) // 32
+        meta = {"kernel": "xattn_core", "flops": 4.0 * rows * hid * nt * 32, "bytes": 4.0 * rows * hid}
+        self._add(lambda s, q=q, o=o: lib.vdmi_xattn_core(q.data_ptr(), hid, o.data_ptr(), kvp, self.B, self.F * hw, self.L,
+                                                          hid // 32, s), meta, name + ".core")
+        y = self._buf(rows, c)
+        b = self._base_args(frames, h, w, y, c, EPI_PLAIN)
+        _fill_pass(b.main, o, hid, None, 0, h, w, 1, [(0, 0)], xa["wout"].data)
+        b.bias = _ptr(xa["bout"])
+        b.has_res, b.res_identity, b.ld_res = 2, _ptr(x), c
+        self._tapgemm(b, name + ".out")
+        return y
+
     def _down(self, name, dn, x, c, h, w) -> torch.Tensor:
         frames = self.B * self.F
         oh, ow = (h + 2 - 4) // 2 + 1, (w + 2 - 4) // 2 + 1
@@ -365,6 +417,8 @@ class Plan:
         lib = _lib.lib()
         P = eng.packed
         B, F, H, W = self.B, self.F, self.H, self.W
+        if self.L:
+            self._setup_context()
         frames = B * F
         dims = u.dims
 
@@ -391,6 +445,8 @@ class Plan:
             if L["sla"] is not None:
                 x = self._sla(f"downs.{i}.2", L["sla"], x, c, h, w)
             x = self._attention(f"downs.{i}.3", L["tattn"], x, c, h, w, True)
+            if self.L:
+                x = self._cross_attention(f"frame_cross_attns_down.{i}", i, x, c, h, w)
             self.taps[f"downs.{i}"] = x
             skips.append((x, c, h, w))
             if L["down"] is not None:
@@ -416,6 +472,8 @@ class Plan:
             if L["sla"] is not None:
                 x = self._sla(f"ups.{i}.2", L["sla"], x, c, h, w)
             x = self._attention(f"ups.{i}.3", L["tattn"], x, c, h, w, True)
+            if self.L:
+                x = self._cross_attention(f"frame_cross_attns_up.{i}", nres + i, x, c, h, w)
             self.taps[f"ups.{i}"] = x
             if L["up"] is not None:
                 x = self._up(f"ups.{i}.4", L["up"], x, c, h, w)
@@ -427,6 +485,14 @@ class Plan:
         self._add(lambda s, x=x: lib.vdmi_final_conv(
             x.data_ptr(), fc["w"].data_ptr(), fc["b"].data_ptr(), self.eps_out.data_ptr(), B, u.dim, F, H, W,
             u.out_dim, s), None, "final_conv.1")
+
+    def run_context(self):
+        """Project ctx_in (masked by ctx_keep) to the packed keys/values of all cross-attention layers."""
+        s = _stream()
+        for call in self.ctx_calls:
+            st = call.fn(s)
+            if st != 0:
+                check(st, call.name)
 
     def run(self):
         """Enqueue every launch on the current stream (no synchronisation)."""
@@ -530,6 +596,31 @@ class UnetEngine:
             "scale": float(dim_head) ** -0.5,
         }
 
+    def _pack_xattn(self, device):
+        """frame_cross_attns_down / _up: Residual(PreNorm(CrossAttention)).  The key/value projections of all
+        layers are stacked into one row GEMM over the context; the out-projection's input columns follow
+        the feature order vdmi_xattn_core writes."""
+        u = self.unet
+        mods = list(u.frame_cross_attns_down) + list(u.frame_cross_attns_up)
+        hid = mods[0].fn.fn.to_q.weight.shape[0]
+        # column 32*head + 16*h + r of the core's output holds feature 32*head + (r&3) + 8*(r>>2) + 4*h
+        perm = torch.tensor([32 * hd + (r & 3) + 8 * (r >> 2) + 4 * hh
+                             for hd in range(hid // 32) for hh in (0, 1) for r in range(16)])
+        layers, wkv = [], []
+        for m in mods:
+            pre, ca = m.fn, m.fn.fn
+            gamma = pre.norm.gamma.detach().float().reshape(-1).cpu()
+            wq = ca.to_q.weight.detach().float().cpu() * gamma[None, :]
+            wo = ca.to_out.weight.detach().float().cpu()[:, perm]
+            layers.append({"wq": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_ATTN, device, want_colsum=True),
+                           "wout": PackedTaps(wo[:, :, None], hid, 0, EPI_PLAIN, device),
+                           "bout": ca.to_out.bias.detach().float().to(device).contiguous()})
+            wkv += [ca.to_k.weight.detach().float().cpu(), ca.to_v.weight.detach().float().cpu()]
+        wkv = torch.cat(wkv, 0)
+        return {"layers": layers, "nl": len(mods), "hid": hid, "ctx_dim": wkv.shape[1],
+                "scale": float(mods[0].fn.fn.scale),
+                "wkv": PackedTaps(wkv[:, :, None], wkv.shape[1], 0, EPI_PLAIN, device)}
+
     def _pack_sla(self, res_mod, device):
         pre = res_mod.fn
         sl = pre.fn
@@ -623,6 +714,8 @@ class UnetEngine:
         fcw = u.final_conv[1].weight
         P["final_conv"] = {"w": f32(fcw.reshape(fcw.shape[0], -1)), "b": f32(u.final_conv[1].bias)}
 
+        P["xattn"] = self._pack_xattn(device) if u.has_frame_cross_attn else None
+
         P["w_all"] = torch.cat(stacked["w"], 0).to(device).contiguous()
         P["b_all"] = torch.cat(stacked["b"], 0).to(device).contiguous()
         P["gamma_all"] = torch.cat(stacked["g"], 0).to(device).contiguous()
@@ -657,24 +750,44 @@ class UnetEngine:
         return self._const_cache[key]
 
     # -- execution -------------------------------------------------------------------------------
-    def plan(self, B, F, H, W, device) -> Plan:
+    def plan(self, B, F, H, W, device, L: int = 0) -> Plan:
+        """L > 0: with the frame cross-attention layers, for contexts of L tokens per sample."""
         self.ensure_packed(device)
-        key = (B, F, H, W, str(device))
+        key = (B, F, H, W, str(device), L)
         if key not in self._plans:
-            self._plans[key] = Plan(self, B, F, H, W, device)
+            self._plans[key] = Plan(self, B, F, H, W, device, L=L)
         return self._plans[key]
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor, time: torch.Tensor, cond=None, null_cond_prob: float = 0.) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, time: torch.Tensor, cond=None, null_cond_prob: float = 0.,
+                frame_cond_features=None, null_frame_cond_prob: float = 0.) -> torch.Tensor:
         if not x.is_cuda:
             raise _lib.VdmiError("Unet3D runs on the HIP device only (no CPU fallback); move the module and inputs to 'cuda'")
         u = self.unet
         B, Cc, F, H, W = x.shape
         if Cc != u.channels:
             raise ValueError(f"expected {u.channels} input channels, got {Cc}")
-        plan = self.plan(B, F, H, W, x.device)
+        L = 0
+        if frame_cond_features is not None and u.has_frame_cross_attn:
+            if frame_cond_features.dim() != 3 or frame_cond_features.shape[0] != B:
+                raise ValueError("frame_cond_features must be (batch, tokens, frame_cond_dim)")
+            L = frame_cond_features.shape[1]
+        plan = self.plan(B, F, H, W, x.device, L)
         plan.x_in.copy_(x.to(torch.float32))
         plan.t_in.copy_(time.to(torch.int64))
+        if L:
+            if frame_cond_features.shape[2] != plan.ctx_in.shape[2]:
+                raise ValueError(f"frame_cond_features has {frame_cond_features.shape[2]} features, "
+                                 f"the model was built with frame_cond_dim={plan.ctx_in.shape[2]}")
+            plan.ctx_in.copy_(frame_cond_features.to(torch.float32))
+            if null_frame_cond_prob > 0:    # reference vdp.py:783-789; prob_mask_like, vdp.py:68-74
+                if null_frame_cond_prob == 1:
+                    plan.ctx_keep.fill_(0)
+                else:
+                    plan.ctx_keep.copy_((torch.rand(B, device=x.device) >= null_frame_cond_prob).to(torch.float32))
+            else:
+                plan.ctx_keep.fill_(1)
+            plan.run_context()
         if u.has_cond:
             plan.cond_in.copy_(cond.to(torch.float32))
             if null_cond_prob == 1:

@@ -137,8 +137,7 @@ class SpatialLinearAttention(_HipOnly):
 
 
 class CrossAttention(_HipOnly):
-    # reference: vdp.py:480-528.  Only runs when frame_cond_features is passed, which
-    # p_sample_loop never does; the parameters exist so checkpoints load.
+    # reference: vdp.py:480-528.  Runs when frame_cond_features is passed (Plan._cross_attention in engine.py).
     def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
         super().__init__()
         inner_dim = dim_head * heads
@@ -321,11 +320,10 @@ class Unet3D(nn.Module):
     ):
         # reference: vdp.py:756-831
         assert not (self.has_cond and not exists(cond)), 'cond must be passed in if cond_dim specified'
-        if exists(frame_cond_features):
-            raise NotImplementedError(
-                "frame cross-attention conditioning is not on the p_sample_loop path and is not built yet")
         if exists(focus_present_mask) or prob_focus_present != 0.:
             raise NotImplementedError("focus-present masking (training-time feature) is not built yet")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
             raise NotImplementedError("the HIP denoiser is forward-only; backward is not built yet")
-        return self.engine().forward(x, time, cond=cond, null_cond_prob=null_cond_prob)
+        return self.engine().forward(x, time, cond=cond, null_cond_prob=null_cond_prob,
+                                     frame_cond_features=frame_cond_features,
+                                     null_frame_cond_prob=null_frame_cond_prob)
