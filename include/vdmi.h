@@ -131,6 +131,7 @@ typedef struct vdmi_tapgemm_args {
                                       (more pixels per workgroup, less weight traffic)        */
     int32_t q_cols;                /* QKV_ATTN: leading output columns that are queries (scaled by
                                       q_scale); 0 = n/3 (q, k, v thirds), n = a query-only projection */
+    int32_t act;                   /* PLAIN only: 0 = none, 1 = SiLU after the bias (before the residual) */
 } vdmi_tapgemm_args;
 
 /* HOST. Tile the library will use for (epilogue, n): *bn = output-channel tile, *bkc = input

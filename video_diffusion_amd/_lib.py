@@ -51,7 +51,7 @@ class TapGemmArgs(C.Structure):
         ("rot_frames", C.c_int32), ("rot_hw", C.c_int32),
         ("out2", C.c_void_p),
         ("sla_hw", C.c_int32), ("tile_bn", C.c_int32),
-        ("q_cols", C.c_int32),
+        ("q_cols", C.c_int32), ("act", C.c_int32),
     ]
 
 

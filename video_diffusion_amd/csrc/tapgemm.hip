@@ -92,6 +92,7 @@ struct KArgs {
     __bf16* out2;
     int sla_hw;
     int heads32;
+    int act;
     unsigned long long* diag;
 };
 
@@ -473,6 +474,14 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
         }
     } else if constexpr (EPI == VDMI_EPI_PLAIN) {
         // bias already in the accumulators
+        if (a.act == 1) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = silu_f(acc[i][j][r]);
+        }
     } else {
         // folded LayerNorm: y = rstd * (acc - mean * colsum)
         float mean[NJ], rstd[NJ];
@@ -755,6 +764,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if (epi == VDMI_EPI_NORM_SILU && !A.gain) return VDMI_E_ARG;
     if ((epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA) && !A.colsum) return VDMI_E_ARG;
     if (epi == VDMI_EPI_QKV_SLA && (!A.out2 || A.sla_hw <= 0)) return VDMI_E_ARG;
+    if (A.act < 0 || A.act > 1 || (A.act && epi != VDMI_EPI_PLAIN)) return VDMI_E_ARG;
     if (A.q_cols < 0 || A.q_cols % 32 || (A.q_cols && epi != VDMI_EPI_QKV_ATTN)) return VDMI_E_ARG;
     if (A.has_res == 2 && (!A.res_identity || A.ld_res % 8 || !aligned16(A.res_identity))) return VDMI_E_ARG;
     if (A.has_res == 1 && epi != VDMI_EPI_NORM_SILU) return VDMI_E_ARG;
@@ -887,6 +897,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         k.colsum = A.colsum;
         k.ln_eps = A.ln_eps;
         k.q_scale = A.q_scale;
+        k.act = A.act;
         k.rot_cos = A.rot_cos;
         k.rot_sin = A.rot_sin;
         k.rot_frames = A.rot_frames > 0 ? A.rot_frames : 1;

@@ -1,10 +1,24 @@
 """VAE and FrameConditioningEncoder with the reference's layers and state-dict keys
 (vdp.py:83-269 of the reference).  They sit outside p_sample_loop (the VAE decodes once after the
-loop, the frame encoder feeds the cross-attention path).  The decoder runs on the HIP library for GPU
-tensors under no_grad (vae_engine.py); the encoder and the frame encoder are plain torch modules.
+loop, the encoder and the frame encoder feed the cross-attention path).  For GPU tensors outside autograd all
+three run on the HIP library (vae_engine.py); the torch layers hold the parameters and serve CPU / training.
 """
 import torch
 from torch import nn
+
+
+def _use_hip(module, x):
+    """GPU tensors outside autograd run on the HIP launch plans (vae_engine.py; they raise if libvdmi.so is
+    missing).  CPU tensors and training (the VAE's own trainer, the frame encoder inside p_losses) keep the
+    torch layers the parameters live in."""
+    return x.is_cuda and not (torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()))
+
+
+def _engine(module, cls_name):
+    if getattr(module, "_hip_engine", None) is None:
+        from . import vae_engine
+        object.__setattr__(module, "_hip_engine", getattr(vae_engine, cls_name)(module))
+    return module._hip_engine
 
 
 class VAEEncoder(nn.Module):
@@ -21,6 +35,8 @@ class VAEEncoder(nn.Module):
         self.to_logvar = nn.Conv3d(base_dim * 4, latent_dim, 1)
 
     def forward(self, x):
+        if _use_hip(self, x):
+            return _engine(self, "VaeEncodeEngine").encode(x)
         h = self.encoder(x)
         return self.to_mean(h), torch.clamp(self.to_logvar(h), -30.0, 20.0)
 
@@ -38,13 +54,8 @@ class VAEDecoder(nn.Module):
         )
 
     def forward(self, z):
-        # GPU tensors outside autograd: the HIP launch plan (vae_engine.py); it raises if libvdmi.so is missing.
-        # CPU tensors and training keep the torch layers the parameters live in.
-        if z.is_cuda and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-            if getattr(self, "_hip_engine", None) is None:
-                from .vae_engine import VaeDecodeEngine
-                object.__setattr__(self, "_hip_engine", VaeDecodeEngine(self))
-            return self._hip_engine.decode(z)
+        if _use_hip(self, z):
+            return _engine(self, "VaeDecodeEngine").decode(z)
         return self.decoder(z)
 
 
@@ -91,6 +102,8 @@ class FrameConditioningEncoder(nn.Module):
         )
 
     def forward(self, prev_latents):
+        if _use_hip(self, prev_latents):
+            return _engine(self, "FrameEncodeEngine").encode(prev_latents)
         features = self.feature_extractor(prev_latents)
         b, c, f, h, w = features.shape
         return features.permute(0, 2, 3, 4, 1).reshape(b, f * h * w, c)
