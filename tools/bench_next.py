@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Timing of the paths next to the denoising loop: frame-conditioned (guided) denoise step, VAE decode / encode,
+frame encoder.  One JSON line per workload; per-kernel-class times come from HIP events on the launch stream.
+
+    python tools/bench_next.py [--batch 16] [--frames 10] [--latent 64] [--prev 4] [--steps 10]
+
+Workloads (random-init weights, synthetic inputs):
+  framecond  Unet3D(dim=64, dim_mults=(1,2,4,8), channels=4) on latents (B,4,F,S,S), conditioning on `prev`
+             previous frames (context = prev * (S/4)^2 tokens of 512 features), frame_cond_scale=1.5: one step =
+             one pass over the doubled batch + guidance + posterior step, replayed as a HIP graph.
+  vae        VAE(channels=3, latent_dim=4, base_dim=64): decode (B,4,F,S,S) -> (B,3,F,8S,8S), encode back.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def timed(fn, steps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def per_call(calls, reps=5):
+    """calls: iterable of (fn(stream), name).  Returns {name: ms per run}."""
+    stream = torch.cuda.current_stream()
+    evs = []
+    for _ in range(reps):
+        for fn, name in calls:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            assert fn(stream.cuda_stream) == 0, name
+            e1.record(stream)
+            evs.append((name, e0, e1))
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1 in evs:
+        out[name] = out.get(name, 0.0) + e0.elapsed_time(e1) / reps
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--frames", type=int, default=10)
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--prev", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from video_diffusion_amd import GaussianDiffusion, Unet3D, VAE
+    from video_diffusion_amd.vae import FrameConditioningEncoder
+    B, F, S = args.batch, args.frames, args.latent
+    torch.manual_seed(0)
+
+    # ---- frame-conditioned guided step ------------------------------------------------------------------
+    unet = Unet3D(dim=64, dim_mults=(1, 2, 4, 8), channels=4).to(dev).eval()
+    enc = FrameConditioningEncoder(4, 512, args.prev).to(dev).eval()
+    with torch.no_grad():
+        feats = enc(torch.randn(B, 4, args.prev, S, S, device=dev))
+    L = feats.shape[1]
+    gd = GaussianDiffusion(unet, torch.nn.Identity(), image_size=8 * S, num_frames=F, channels=3, timesteps=1000).to(dev)
+    gd.noise_source = "philox"
+    shape = (B, 4, F, S, S)
+    for guided, scale in ((True, 1.5), (False, 1.0)):
+        t0 = time.perf_counter()
+        gd.frame_cond_sample_loop(shape, feats, scale, steps=3)          # builds plan + graph
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        gd.frame_cond_sample_loop(shape, feats, scale, steps=3)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        gd.frame_cond_sample_loop(shape, feats, scale, steps=3 + args.steps)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        ms = ((t3 - t2) - (t2 - t1)) / args.steps * 1e3               # marginal cost of a step (set-up cancels)
+        rep = 2 if guided else 1
+        plan = unet.engine().plan(rep * B, F, S, S, dev, L)
+        # per kernel class (names repeat per layer)
+        pc2 = {}
+        stream = torch.cuda.current_stream()
+        evs = []
+        for _ in range(5):
+            for c in plan.calls:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                assert c.fn(stream.cuda_stream) == 0
+                e1.record(stream)
+                evs.append((c, e0, e1))
+        torch.cuda.synchronize()
+        for c, e0, e1 in evs:
+            k = (c.args or {}).get("kernel", c.name.split(".")[-1])
+            d = pc2.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+            d["ms"] += e0.elapsed_time(e1) / 5
+            d["flops"] += (c.args or {}).get("flops", 0.0) / 5
+            d["bytes"] += (c.args or {}).get("bytes", 0.0) / 5
+            d["n"] += 1
+        ctx = per_call([(c.fn, c.name) for c in plan.ctx_calls])
+        xa = pc2.get("xattn_core", {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 5})
+        print(json.dumps({
+            "workload": f"framecond {'guided x1.5 (doubled batch)' if guided else 'scale 1'}: latents {shape}, context {L} tokens",
+            "ms_per_step": round(ms, 3), "first_call_s": round(t1 - t0, 2),
+            "context_kv_ms_once_per_loop": {k: round(v, 4) for k, v in ctx.items()},
+            "xattn_core": {"ms_per_step": round(xa["ms"], 4), "launches": xa["n"] // 5,
+                           "tflops": round(xa["flops"] / (xa["ms"] * 1e-3) / 1e12, 1) if xa["ms"] else None,
+                           "alg_gbs": round(xa["bytes"] / (xa["ms"] * 1e-3) / 1e9, 1) if xa["ms"] else None},
+            "classes_ms": {k: round(v["ms"], 4) for k, v in sorted(pc2.items(), key=lambda kv: -kv[1]["ms"])},
+        }), flush=True)
+
+    # ---- VAE ---------------------------------------------------------------------------------------------
+    vae = VAE(channels=3, latent_dim=4, base_dim=64).to(dev).eval()
+    z = torch.randn(B, 4, F, S, S, device=dev)
+    with torch.no_grad():
+        x = vae.decode(z)
+        dec_ms = timed(lambda: vae.decode(z), args.steps)
+        enc_ms = timed(lambda: vae.encode(x), args.steps)
+        fe_ms = timed(lambda: enc(torch.randn(B, 4, args.prev, S, S, device=dev)), args.steps)
+    dplan = next(iter(vae.decoder._hip_engine._plans.values()))
+    eplan = next(iter(vae.encoder._hip_engine._plans.values()))
+    out_bytes = x.numel() * 4
+    print(json.dumps({
+        "workload": f"vae: decode {tuple(z.shape)} -> {tuple(x.shape)}, encode back; frame encoder on {args.prev} frames",
+        "decode_ms": round(dec_ms, 3), "encode_ms": round(enc_ms, 3), "frame_encoder_ms": round(fe_ms, 3),
+        "decode_output_gbs": round(out_bytes / (dec_ms * 1e-3) / 1e9, 1),
+        "decode_calls_ms": {k: round(v, 4) for k, v in per_call(dplan.calls).items()},
+        "encode_calls_ms": {k: round(v, 4) for k, v in per_call(eplan.calls).items()},
+    }), flush=True)
+
+
+if __name__ == "__main__":
+    main()
