@@ -189,9 +189,11 @@ int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64_t rows_per
  * qkv: bf16 [rows][3*heads*32] (q already scaled and rotated), out: bf16 [rows][heads*32].
  * Row m = outer*(n_tok*tok_stride) + i*tok_stride + inner; tokens of one group share
  * (outer, inner).  bias: float [heads][n_tok][n_tok] or NULL.  dim_head is 32.
+ * focus: uint8 [rows / rows_per_sample] or NULL — the focus-present mask of vdp.py:590-600: in a
+ * sample whose flag is set every token attends only to itself (output = its own v).
  * ------------------------------------------------------------------------------------------ */
 int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int heads, int n_tok, int64_t tok_stride,
-                   const float* bias, vdmi_stream stream);
+                   const float* bias, const uint8_t* focus, int64_t rows_per_sample, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused temporal attention: Residual(PreNorm(EinopsToAndFrom('b c f h w','b (h w) f c', Attention)))
@@ -199,13 +201,14 @@ int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int heads, int n_to
  * q scaling, rotary, q.k^T + relative-position bias, softmax over the f frames of each site, .v,
  * to_out and the residual add.  x, y: bf16 [b*f*hw][c] (y may not alias x); c in {32, 64, 128},
  * f <= 32, dim_head 32.  wpack: vdmi_pack_tattn output.  bias: float [heads][f][f] or NULL;
- * rot_cos/rot_sin: float [f][16] or NULL (no rotary).
+ * rot_cos/rot_sin: float [f][16] or NULL (no rotary).  focus: uint8 [b] or NULL, the focus-present
+ * mask of vdp.py:590-600 (flagged samples: every frame attends only to itself).
  * ------------------------------------------------------------------------------------------ */
 size_t vdmi_pack_tattn_elems(int c, int heads);                                           /* HOST */
 int vdmi_pack_tattn(const float* wqkv_gamma_folded, const float* wout, int c, int heads, uint16_t* out);  /* HOST */
 int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const float* bias, const float* rot_cos,
                      const float* rot_sin, int b, int f, int hw, int c, int heads, float q_scale, float eps,
-                     vdmi_stream stream);
+                     const uint8_t* focus, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused Residual(PreNorm(SpatialLinearAttention)) (vdp.py:454-479, 331-337, 380-408): three

@@ -3,7 +3,8 @@
     python -m oracle.make_golden_framecond
 
 The reference's Unet3D is run with frame_cond_features from the reference's FrameConditioningEncoder:
-conditioning kept, dropped (null_frame_cond_prob = 1) and dropped for one sample of the batch.  Inputs
+conditioning kept, dropped (null_frame_cond_prob = 1) and dropped for one sample of the batch; and without
+conditioning but with the focus-present mask set for one sample / for all.  Inputs
 and outputs only; weights come from oracle.weightgen (Unet3D salt 0, encoder salt 11).
 TEST INFRASTRUCTURE.
 """
@@ -41,7 +42,10 @@ def main():
          eps_cond=m(x, t, frame_cond_features=feats, null_frame_cond_prob=0.),
          eps_null=m(x, t, frame_cond_features=feats, null_frame_cond_prob=1.),
          keep_mixed=keep, eps_mixed=m(x, t, frame_cond_features=feats * keep[:, None, None]),
-         eps_plain=m(x, t))
+         eps_plain=m(x, t),
+         focus_mixed=torch.tensor([True, False]),
+         eps_focus_mixed=m(x, t, focus_present_mask=torch.tensor([True, False])),
+         eps_focus_all=m(x, t, prob_focus_present=1.))
 
 
 if __name__ == "__main__":

@@ -200,9 +200,9 @@ def rotary_interleaved(t: Tensor, rot_dim: int) -> Tensor:
 # A6/A9  softmax attention over a token axis (vdp.py:546-612)
 # --------------------------------------------------------------------------
 def attention_tokens(x: Tensor, w_qkv: Tensor, w_out: Tensor, heads: int, dim_head: int,
-                     rotary: bool, pos_bias: Optional[Tensor]) -> Tensor:
-    """x: [..., n, C] -> [..., n, C].  The focus-present mask is all-False on the
-    sampling path (vdp.py:590 is then skipped) and is not restated."""
+                     rotary: bool, pos_bias: Optional[Tensor], focus: Optional[Tensor] = None) -> Tensor:
+    """x: [..., n, C] -> [..., n, C].  focus: bool [b] (x is [b, ., n, C]) — the focus-present mask of
+    vdp.py:590-600: in flagged samples a token attends only to itself.  All-False on the sampling path."""
     lead = x.shape[:-2]
     n = x.shape[-2]
     qkv = F.linear(x, w_qkv)
@@ -220,6 +220,10 @@ def attention_tokens(x: Tensor, w_qkv: Tensor, w_out: Tensor, heads: int, dim_he
     sim = q @ k.transpose(-1, -2)
     if pos_bias is not None:
         sim = sim + pos_bias
+    if focus is not None and bool(focus.any()):
+        eye = torch.eye(n, dtype=torch.bool)
+        keep = torch.where(focus.view(-1, 1, 1, 1, 1), eye.view(1, 1, 1, n, n), torch.ones(1, 1, 1, n, n, dtype=torch.bool))
+        sim = sim.masked_fill(~keep, -torch.finfo(sim.dtype).max)
     sim = sim - sim.amax(dim=-1, keepdim=True)
     attn = sim.softmax(dim=-1)
     out = attn @ v
@@ -227,13 +231,14 @@ def attention_tokens(x: Tensor, w_qkv: Tensor, w_out: Tensor, heads: int, dim_he
     return F.linear(out, w_out)
 
 
-def temporal_attn_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg, pos_bias: Tensor) -> Tensor:
+def temporal_attn_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg, pos_bias: Tensor,
+                           focus: Optional[Tensor] = None) -> Tensor:
     """Residual(PreNorm(EinopsToAndFrom('b c f h w','b (h w) f c', Attention))) — vdp.py:636,645."""
     b, c, f, h, w = x.shape
     y = layernorm_c(x, sd[p + ".fn.norm.gamma"])
     tok = y.permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
     o = attention_tokens(tok, sd[p + ".fn.fn.fn.to_qkv.weight"], sd[p + ".fn.fn.fn.to_out.weight"],
-                         cfg.attn_heads, cfg.attn_dim_head, cfg.rotary, pos_bias)
+                         cfg.attn_heads, cfg.attn_dim_head, cfg.rotary, pos_bias, focus)
     o = o.reshape(b, h, w, f, c).permute(0, 4, 3, 1, 2)
     return o + x
 
@@ -319,8 +324,10 @@ def upsample(sd: SD, p: str, x: Tensor) -> Tensor:
 # --------------------------------------------------------------------------
 def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
                    cond: Optional[Tensor] = None, null_cond: bool = False,
-                   frame_cond: Optional[Tensor] = None, frame_keep: Optional[Tensor] = None) -> Tensor:
-    """focus_present_mask all-False (what p_sample passes, vdp.py:978-983).
+                   frame_cond: Optional[Tensor] = None, frame_keep: Optional[Tensor] = None,
+                   focus: Optional[Tensor] = None) -> Tensor:
+    """``focus`` bool [B] is the focus-present mask (all-False is what p_sample passes, vdp.py:978-983); it
+    reaches every temporal attention except init_temporal_attn (vdp.py:773, 800, 812, 821).
 
     ``null_cond`` selects null_cond_prob = 1 (True) or 0 (False) — the two values
     forward_with_cond_scale uses (vdp.py:739,747).  ``frame_cond`` [B, L, frame_cond_dim] switches on the
@@ -350,7 +357,7 @@ def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
         x = resnet_block(sd, p + ".1", x, t)
         if cfg.use_sparse_linear_attn:
             x = sla_residual(sd, p + ".2", x, cfg)
-        x = temporal_attn_residual(sd, p + ".3", x, cfg, bias)
+        x = temporal_attn_residual(sd, p + ".3", x, cfg, bias, focus)
         if frame_cond is not None:
             x = cross_attn_residual(sd, f"frame_cross_attns_down.{i}", x, frame_cond, cfg.attn_heads, cfg.attn_dim_head)
         skips.append(x)
@@ -359,7 +366,7 @@ def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
 
     x = resnet_block(sd, "mid_block1", x, t)
     x = spatial_attn_residual(sd, "mid_spatial_attn", x, cfg)
-    x = temporal_attn_residual(sd, "mid_temporal_attn", x, cfg, bias)
+    x = temporal_attn_residual(sd, "mid_temporal_attn", x, cfg, bias, focus)
     x = resnet_block(sd, "mid_block2", x, t)
 
     for i in range(nres):
@@ -369,7 +376,7 @@ def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
         x = resnet_block(sd, p + ".1", x, t)
         if cfg.use_sparse_linear_attn:
             x = sla_residual(sd, p + ".2", x, cfg)
-        x = temporal_attn_residual(sd, p + ".3", x, cfg, bias)
+        x = temporal_attn_residual(sd, p + ".3", x, cfg, bias, focus)
         if frame_cond is not None:
             x = cross_attn_residual(sd, f"frame_cross_attns_up.{i}", x, frame_cond, cfg.attn_heads, cfg.attn_dim_head)
         if i < nres - 1:

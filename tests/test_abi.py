@@ -82,7 +82,7 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.vdmi_tapgemm(None, None) == -1
     a = _lib.TapGemmArgs()
     assert lib.vdmi_tapgemm(C.byref(a), None) == -1           # null output
-    assert lib.vdmi_attn_core(None, None, 0, 8, 10, 1, None, None) == -1
+    assert lib.vdmi_attn_core(None, None, 0, 8, 10, 1, None, None, 0, None) == -1
     assert lib.vdmi_ddpm_step(None, None, None, None, None, None, 1, 1, 1, 0, 0, None) == -1
     bn, bkc = C.c_int(), C.c_int()
     assert lib.vdmi_tapgemm_tile(_lib.EPI_NORM_SILU, 64, C.byref(bn), C.byref(bkc)) == 0 and bn.value == 64

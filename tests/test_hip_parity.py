@@ -336,6 +336,35 @@ def test_unet_frame_conditioning_vs_reference():
         assert rel_err(g["eps_cond"], g["eps_plain"]) > 5 * MODEL_TOL
 
 
+def test_focus_present_mask_vs_reference():
+    """focus_present_mask / prob_focus_present (reference vdp.py:590-600, 769) through the fused temporal attention."""
+    g = golden("tiny_framecond")
+    m = make_unet(**TINY).to(dev())
+    x = inp("fc.x", tuple(int(v) for v in g["x_shape"])).to(dev())
+    t = g["t"].to(dev())
+    with torch.no_grad():
+        assert rel_err(m(x, t, focus_present_mask=g["focus_mixed"].to(dev())).cpu(), g["eps_focus_mixed"]) < MODEL_TOL
+        assert rel_err(m(x, t, prob_focus_present=1.).cpu(), g["eps_focus_all"]) < MODEL_TOL
+        assert rel_err(m(x, t).cpu(), g["eps_plain"]) < MODEL_TOL          # and the flags reset
+    assert rel_err(g["eps_focus_mixed"], g["eps_plain"]) > 5 * MODEL_TOL
+
+
+def test_focus_present_mask_wide_channels_vs_oracle():
+    """The same mask through the unfused attention core (256-channel level)."""
+    kw = dict(dim=64, dim_mults=(1, 4), channels=3)
+    m = make_unet(salt=5, **kw)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = inp("focus.x", (3, 3, 5, 8, 8))
+    t = torch.tensor([10, 500, 999])
+    focus = torch.tensor([False, True, True])
+    with torch.no_grad():
+        ref = O.unet3d_forward(sd, oracle_cfg(**kw), x, t, focus=focus)
+        plain = O.unet3d_forward(sd, oracle_cfg(**kw), x, t)
+        out = m.to(dev())(x.to(dev()), t.to(dev()), focus_present_mask=focus.to(dev()))
+    assert rel_err(out.cpu(), ref) < MODEL_TOL
+    assert rel_err(ref, plain) > 5 * MODEL_TOL
+
+
 @pytest.mark.parametrize("scale", [1.0, 1.5])
 def test_frame_cond_sample_loop_vs_oracle(scale):
     """The frame-conditioned loop of sample() (doubled-batch guidance, cached keys/values) against the oracle's

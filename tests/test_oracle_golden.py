@@ -177,3 +177,5 @@ def test_frame_conditioning_oracle_matches_reference_golden():
         assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], frame_cond=f), g["eps_cond"]) < 1e-5
         assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], frame_cond=f, frame_keep=torch.zeros(2)), g["eps_null"]) < 1e-5
         assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], frame_cond=f, frame_keep=g["keep_mixed"]), g["eps_mixed"]) < 1e-5
+        assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], focus=g["focus_mixed"]), g["eps_focus_mixed"]) < 1e-5
+        assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], focus=torch.tensor([True, True])), g["eps_focus_all"]) < 1e-5

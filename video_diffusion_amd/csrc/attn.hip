@@ -9,7 +9,8 @@ namespace {
 
 __global__ __launch_bounds__(256) void attn_core_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
                                                         long long rows, int heads, int n_tok, long long tok_stride,
-                                                        const float* __restrict__ bias) {
+                                                        const float* __restrict__ bias, const uint8_t* __restrict__ focus,
+                                                        long long rows_per_sample) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long m = gid / heads;
     const int hd = (int)(gid - m * heads);
@@ -34,7 +35,9 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const __bf16* __restrict
     for (int e = 0; e < 32; ++e) o[e] = 0.f;
     float mx = -INFINITY, l = 0.f;
     const float* brow = bias ? bias + ((long long)hd * n_tok + i) * n_tok : nullptr;
+    const bool self_only = focus && focus[m / rows_per_sample];   // vdp.py:590-600: every other key is masked out
     for (int j = 0; j < n_tok; ++j) {
+        if (self_only && j != i) continue;
         const long long mj = base + (long long)j * tok_stride;
         const bf16x8* kp = reinterpret_cast<const bf16x8*>(qkv + mj * ld + hid + hd * 32);
         const bf16x8* vp = reinterpret_cast<const bf16x8*>(qkv + mj * ld + 2 * hid + hd * 32);
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const __bf16* __restrict
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_core_lds_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
                                                             long long rows, int heads, int n_tok, long long tok_stride,
-                                                            const float* __restrict__ bias, int gpb, long long ngroups) {
+                                                            const float* __restrict__ bias, int gpb, long long ngroups,
+                                                            const uint8_t* __restrict__ focus, long long rows_per_sample) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hid = heads * 32, ld = 3 * hid;
     const int krow = 2 * hid + 8;                        // padded k|v row (elements)
@@ -117,7 +121,9 @@ __global__ __launch_bounds__(256) void attn_core_lds_kernel(const __bf16* __rest
         float mx = -INFINITY, l = 0.f;
         const float* brow = bias ? bias + ((long long)hd * n_tok + i) * n_tok : nullptr;
         const __bf16* kb = kv + (g * n_tok) * krow + hd * 32;
+        const bool self_only = focus && focus[m / rows_per_sample];
         for (int j = 0; j < n_tok; ++j) {
+            if (self_only && j != i) continue;
             const bf16x8* kp = reinterpret_cast<const bf16x8*>(kb + j * krow);
             const bf16x8* vp = reinterpret_cast<const bf16x8*>(kb + j * krow + hid);
             float sc = brow ? brow[j] : 0.f;
@@ -297,8 +303,10 @@ __global__ __launch_bounds__(256) void sla_context_kernel(const __bf16* __restri
 }   // namespace
 
 extern "C" int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int heads, int n_tok, int64_t tok_stride,
-                              const float* bias, vdmi_stream stream) {
+                              const float* bias, const uint8_t* focus, int64_t rows_per_sample, vdmi_stream stream) {
     if (!qkv || !out) return VDMI_E_ARG;
+    if (focus && (rows_per_sample <= 0 || rows % rows_per_sample)) return VDMI_E_SHAPE;
+    if (!focus) rows_per_sample = rows > 0 ? rows : 1;
     if (rows <= 0 || heads <= 0 || n_tok <= 0 || tok_stride <= 0 || rows % ((int64_t)n_tok * tok_stride))
         return VDMI_E_SHAPE;
     if (!aligned16(qkv) || !aligned16(out)) return VDMI_E_ALIGN;
@@ -320,7 +328,7 @@ extern "C" int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int head
             if (nb > 0x7fffffffLL) return VDMI_E_SHAPE;
             hipLaunchKernelGGL(attn_core_lds_kernel, dim3((unsigned)nb), dim3(256), lds, static_cast<hipStream_t>(stream),
                                static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), (long long)rows, heads, n_tok,
-                               (long long)tok_stride, bias, gpb, ngroups);
+                               (long long)tok_stride, bias, gpb, ngroups, focus, (long long)rows_per_sample);
             VDMI_LAUNCH_CHECK();
             return VDMI_OK;
         }
@@ -330,7 +338,7 @@ extern "C" int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int head
     if (blocks > 0x7fffffffLL) return VDMI_E_SHAPE;
     hipLaunchKernelGGL(attn_core_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), (long long)rows, heads, n_tok,
-                       (long long)tok_stride, bias);
+                       (long long)tok_stride, bias, focus, (long long)rows_per_sample);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }

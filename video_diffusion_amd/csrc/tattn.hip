@@ -36,6 +36,7 @@ struct TAttnArgs {
     const float* bias;      // [heads][F][F] or null
     const float* rot_cos;   // [F][16] or null
     const float* rot_sin;
+    const uint8_t* focus;   // [B] or null: samples whose frames attend only to themselves (vdp.py:590-600)
     int F, HW, heads;
     int sites_per_group;    // floor(32 / F)
     int groups_per_sample;  // ceil(HW / sites_per_group): groups never straddle samples, so a sample's
@@ -81,11 +82,12 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
 
     // per-lane constants: this lane's row as a query / row of x, and the 16 key rows of its registers
     const int q_site = l31 / F, q_f = l31 - q_site * F;
-    unsigned kmask = 0;
+    unsigned kmask_all = 0, kmask_self = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ks = acc_row(r, half) / F;
-        if (ks == q_site && ks < g) kmask |= 1u << r;
+        if (ks == q_site && ks < g) kmask_all |= 1u << r;
+        if (acc_row(r, half) == l31 && ks < g) kmask_self |= 1u << r;
     }
     f32x4 rc[2], rs[2];
 #pragma unroll
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
         const int b = grp / a.groups_per_sample;
         const int s = (grp - b * a.groups_per_sample) * g + q_site;      // site within the sample
         const bool rowvalid = grp < a.ngroups && q_site < g && s < a.HW;
+        const unsigned kmask = (a.focus && grp < a.ngroups && a.focus[b]) ? kmask_self : kmask_all;
         const long long grow = rowvalid ? ((long long)b * F + q_f) * a.HW + s : 0;
         // ---- load this lane's row (8*KS values) and LayerNorm it in registers -------------------
         bf16x8 xh[KS];
@@ -295,7 +298,7 @@ extern "C" int vdmi_pack_tattn(const float* wqkv, const float* wout, int c, int 
 
 extern "C" int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const float* bias, const float* rot_cos,
                                 const float* rot_sin, int b, int f, int hw, int c, int heads, float q_scale,
-                                float eps, vdmi_stream stream) {
+                                float eps, const uint8_t* focus, vdmi_stream stream) {
     if (!x || !y || !wpack) return VDMI_E_ARG;
     if (b <= 0 || f <= 0 || f > 32 || hw <= 0 || heads <= 0 || (rot_cos && !rot_sin)) return VDMI_E_SHAPE;
     if (!aligned16(x) || !aligned16(y) || !aligned16(wpack)) return VDMI_E_ALIGN;
@@ -306,6 +309,7 @@ extern "C" int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const
     a.bias = bias;
     a.rot_cos = rot_cos;
     a.rot_sin = rot_sin;
+    a.focus = focus;
     a.F = f;
     a.HW = hw;
     a.heads = heads;

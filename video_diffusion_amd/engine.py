@@ -100,6 +100,7 @@ class Plan:
         self.t_in = torch.zeros(B, device=device, dtype=torch.int64)
         self.cond_in = torch.zeros(B, u.cond_dim, device=device, dtype=torch.float32) if u.has_cond else None
         self.null_mask = torch.zeros(B, device=device, dtype=torch.uint8) if u.has_cond else None
+        self.focus_in = torch.zeros(B, device=device, dtype=torch.uint8)     # focus-present mask, all False by default
         self.eps_out = torch.empty(B, u.out_dim, F, H, W, device=device, dtype=torch.float32)
         self.taps: Dict[str, torch.Tensor] = {}   # named intermediate activations (for tests)
         self._setup()
@@ -221,8 +222,10 @@ class Plan:
             res = ("identity", srcs[0][0])
         return self._block(name + ".block2", (rb["w2"], rb["b2"]), [(hbuf, cmid)], h, w, rb["gamma2"], None, 0, res)
 
-    def _attention(self, name, at, x, c, h, w, temporal: bool) -> torch.Tensor:
-        """Residual(PreNorm(Attention)) over frames (temporal) or over the h*w positions (spatial)."""
+    def _attention(self, name, at, x, c, h, w, temporal: bool, focus: bool = False) -> torch.Tensor:
+        """Residual(PreNorm(Attention)) over frames (temporal) or over the h*w positions (spatial).
+        focus: the layer receives the focus-present mask (self.focus_in, reference vdp.py:800, 812, 821)."""
+        fptr = self.focus_in.data_ptr() if focus else None
         lib = _lib.lib()
         frames, hw = self.B * self.F, h * w
         rows = frames * hw
@@ -234,7 +237,7 @@ class Plan:
                     "bytes": 4.0 * rows * c}
             self._add(lambda s, x=x, y=y: lib.vdmi_tattn_fused(
                 x.data_ptr(), y.data_ptr(), wp.data_ptr(), _ptr(self.pos_bias), _ptr(self.rot_cos),
-                _ptr(self.rot_sin), self.B, self.F, hw, c, hid // 32, at["scale"], 1e-5, s), meta, name + ".fused")
+                _ptr(self.rot_sin), self.B, self.F, hw, c, hid // 32, at["scale"], 1e-5, fptr, s), meta, name + ".fused")
             return y
         qkv = self._buf(rows, 3 * hid)
         a = self._base_args(frames, h, w, qkv, 3 * hid, EPI_QKV_ATTN)
@@ -252,7 +255,7 @@ class Plan:
         else:
             n_tok, stride, bias = hw, 1, None
         self._add(lambda s, qkv=qkv, o=o, bias=bias: lib.vdmi_attn_core(
-            qkv.data_ptr(), o.data_ptr(), rows, heads, n_tok, stride, _ptr(bias), s), None, name + ".core")
+            qkv.data_ptr(), o.data_ptr(), rows, heads, n_tok, stride, _ptr(bias), fptr, self.F * hw, s), None, name + ".core")
         y = self._buf(rows, c)
         b = self._base_args(frames, h, w, y, c, EPI_PLAIN)
         _fill_pass(b.main, o, hid, None, 0, h, w, 1, [(0, 0)], at["wout"].data)
@@ -444,7 +447,7 @@ class Plan:
             x = self._resnet(f"downs.{i}.1", L["rb1"], [(x, c)], h, w)
             if L["sla"] is not None:
                 x = self._sla(f"downs.{i}.2", L["sla"], x, c, h, w)
-            x = self._attention(f"downs.{i}.3", L["tattn"], x, c, h, w, True)
+            x = self._attention(f"downs.{i}.3", L["tattn"], x, c, h, w, True, focus=True)
             if self.L:
                 x = self._cross_attention(f"frame_cross_attns_down.{i}", i, x, c, h, w)
             self.taps[f"downs.{i}"] = x
@@ -455,7 +458,7 @@ class Plan:
 
         x = self._resnet("mid_block1", P["mid_block1"], [(x, c)], h, w)
         x = self._attention("mid_spatial_attn", P["mid_spatial_attn"], x, c, h, w, False)
-        x = self._attention("mid_temporal_attn", P["mid_temporal_attn"], x, c, h, w, True)
+        x = self._attention("mid_temporal_attn", P["mid_temporal_attn"], x, c, h, w, True, focus=True)
         x = self._resnet("mid_block2", P["mid_block2"], [(x, c)], h, w)
         self.taps["mid"] = x
 
@@ -471,7 +474,7 @@ class Plan:
             x = self._resnet(f"ups.{i}.1", L["rb1"], [(x, c)], h, w)
             if L["sla"] is not None:
                 x = self._sla(f"ups.{i}.2", L["sla"], x, c, h, w)
-            x = self._attention(f"ups.{i}.3", L["tattn"], x, c, h, w, True)
+            x = self._attention(f"ups.{i}.3", L["tattn"], x, c, h, w, True, focus=True)
             if self.L:
                 x = self._cross_attention(f"frame_cross_attns_up.{i}", nres + i, x, c, h, w)
             self.taps[f"ups.{i}"] = x
@@ -760,7 +763,8 @@ class UnetEngine:
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, time: torch.Tensor, cond=None, null_cond_prob: float = 0.,
-                frame_cond_features=None, null_frame_cond_prob: float = 0.) -> torch.Tensor:
+                frame_cond_features=None, null_frame_cond_prob: float = 0., focus_present_mask=None,
+                prob_focus_present: float = 0.) -> torch.Tensor:
         if not x.is_cuda:
             raise _lib.VdmiError("Unet3D runs on the HIP device only (no CPU fallback); move the module and inputs to 'cuda'")
         u = self.unet
@@ -788,6 +792,15 @@ class UnetEngine:
             else:
                 plan.ctx_keep.fill_(1)
             plan.run_context()
+        # reference vdp.py:769: the mask defaults to prob_mask_like((batch,), prob_focus_present)
+        if focus_present_mask is not None:
+            plan.focus_in.copy_(focus_present_mask.to(device=x.device, dtype=torch.uint8))
+        elif prob_focus_present == 1:
+            plan.focus_in.fill_(1)
+        elif prob_focus_present == 0:
+            plan.focus_in.fill_(0)
+        else:
+            plan.focus_in.copy_((torch.rand(B, device=x.device) < prob_focus_present).to(torch.uint8))
         if u.has_cond:
             plan.cond_in.copy_(cond.to(torch.float32))
             if null_cond_prob == 1:

@@ -320,10 +320,9 @@ class Unet3D(nn.Module):
     ):
         # reference: vdp.py:756-831
         assert not (self.has_cond and not exists(cond)), 'cond must be passed in if cond_dim specified'
-        if exists(focus_present_mask) or prob_focus_present != 0.:
-            raise NotImplementedError("focus-present masking (training-time feature) is not built yet")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
             raise NotImplementedError("the HIP denoiser is forward-only; backward is not built yet")
         return self.engine().forward(x, time, cond=cond, null_cond_prob=null_cond_prob,
                                      frame_cond_features=frame_cond_features,
-                                     null_frame_cond_prob=null_frame_cond_prob)
+                                     null_frame_cond_prob=null_frame_cond_prob,
+                                     focus_present_mask=focus_present_mask, prob_focus_present=prob_focus_present)
