@@ -11,7 +11,8 @@
 //   S^T [key x query] = K (A operand, from the pack) * Q^T (B operand, 16-byte loads of the q rows)
 //   online softmax over the key tiles in the log2 domain (q is pre-multiplied by scale * log2 e)
 //   O^T [d x query]  += V^T (A operand, keys in accumulator-row order) * P^T (the S^T registers themselves)
-// so no LDS and no barrier is needed; the K/V pack of a sample (heads * ceil(L/32) * 4 KB) stays in L2.
+// A workgroup is 8 such waves of one sample; it stages the keys/values of a (head, 8 key tiles) step in LDS once
+// (double buffered, one barrier per step), so the pack is read from L2 once per 256 queries, not once per 32.
 // A lane ends with 16 features of its query row for the head; they are stored as 32 contiguous bytes at
 // column head*32 + half*16, i.e. in a permuted feature order that the out-projection's packed weights undo.
 #include "vdmi_common.h"
@@ -77,16 +78,20 @@ struct XCoreArgs {
     __bf16* o;
     const __bf16* kv;       // this layer: [b][2][heads][nt][2][64][8]
     long long rows_per_sample;
-    int ldq, heads, l, nt, groups_per_sample, ngroups;
+    int ldq, heads, l, nt, groups_per_sample, blocks_per_sample;
 };
 
-__global__ __launch_bounds__(256) void xattn_core_kernel(const XCoreArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-    const int grp = blockIdx.x * 4 + wave;
-    if (grp >= a.ngroups) return;                       // whole waves leave; the kernel has no barrier
-    const int b = grp / a.groups_per_sample;
-    const long long row = (long long)(grp - b * a.groups_per_sample) * 32 + l31;
-    const bool valid = row < a.rows_per_sample;
+constexpr int XC_WAVES = 8;          // waves (= 32-query groups) per workgroup, all of one sample
+constexpr int XC_CH = 8;             // key tiles staged per step: 8 * 4 KB, double buffered
+constexpr int XC_PP = XC_CH * 256 / (XC_WAVES * 64);   // 16-byte pieces per thread per step
+
+__global__ __launch_bounds__(XC_WAVES * 64) void xattn_core_kernel(const XCoreArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 kvbuf[2][XC_CH * 2048];   // per tile: K (2 fragments), V (2 fragments)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x / a.blocks_per_sample;
+    const int grp = (blockIdx.x - b * a.blocks_per_sample) * XC_WAVES + wave;      // 32-row group inside the sample
+    const long long row = (long long)grp * 32 + l31;
+    const bool valid = grp < a.groups_per_sample && row < a.rows_per_sample;
     const long long grow = (long long)b * a.rows_per_sample + (valid ? row : 0);
     const int hid = a.heads * 32;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -96,6 +101,36 @@ __global__ __launch_bounds__(256) void xattn_core_kernel(const XCoreArgs a) {
     for (int r = 0; r < 16; ++r)
         if (acc_row(r, half) < tail) tailmask |= 1u << r;
 
+    // staging: step = (head, chunk of XC_CH key tiles); the keys/values of a step are read from L2 once per
+    // workgroup (not once per wave), global -> registers during the previous step, registers -> LDS after it
+    const int nchunks = (a.nt + XC_CH - 1) / XC_CH, nsteps = a.heads * nchunks;
+    bf16x8 pre[XC_PP];
+    auto prefetch = [&](int step) {
+        const int head = step / nchunks, t0 = (step - head * nchunks) * XC_CH;
+        const int cnt = min(XC_CH, a.nt - t0);
+        const __bf16* kb = a.kv + (((long long)(b * 2 + 0) * a.heads + head) * a.nt + t0) * 1024;
+        const __bf16* vb = a.kv + (((long long)(b * 2 + 1) * a.heads + head) * a.nt + t0) * 1024;
+#pragma unroll
+        for (int p = 0; p < XC_PP; ++p) {
+            const int idx = tid + p * (XC_WAVES * 64);
+            const int tt = idx >> 8, within = idx & 255;
+            if (tt < cnt)
+                pre[p] = *reinterpret_cast<const bf16x8*>((within < 128 ? kb : vb - 1024) + tt * 1024 + within * 8);
+        }
+    };
+    auto commit = [&](int step) {
+        const int head = step / nchunks, t0 = (step - head * nchunks) * XC_CH;
+        const int cnt = min(XC_CH, a.nt - t0);
+        __bf16* dst = kvbuf[step & 1];
+#pragma unroll
+        for (int p = 0; p < XC_PP; ++p) {
+            const int idx = tid + p * (XC_WAVES * 64);
+            if ((idx >> 8) < cnt) *reinterpret_cast<bf16x8*>(dst + idx * 8) = pre[p];
+        }
+    };
+
+    prefetch(0);
+    int step = 0;
     for (int head = 0; head < a.heads; ++head) {
         const __bf16* qp = a.q + grow * a.ldq + head * 32 + 8 * half;
         bf16x8 q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0;
@@ -103,41 +138,58 @@ __global__ __launch_bounds__(256) void xattn_core_kernel(const XCoreArgs a) {
             q0 = *reinterpret_cast<const bf16x8*>(qp);
             q1 = *reinterpret_cast<const bf16x8*>(qp + 16);
         }
-        const __bf16* kp = a.kv + (((long long)(b * 2 + 0) * a.heads + head) * a.nt) * 1024 + lane * 8;
-        const __bf16* vp = a.kv + (((long long)(b * 2 + 1) * a.heads + head) * a.nt) * 1024 + lane * 8;
-        float m = -1e30f, lsum = 0.f;
-        f32x16 o = zero;
-        for (int t = 0; t < a.nt; ++t) {
-            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp + t * 1024);
-            const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kp + t * 1024 + 512);
-            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vp + t * 1024);
-            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(vp + t * 1024 + 512);
-            f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, zero, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q1, st, 0, 0, 0);
-            if (t == a.nt - 1) {
+        float m = 0.f, lsum = 0.f;          // the first tile of a head always sets m to its own maximum
+        f32x16 o = zero, negm = zero;
+        for (int c = 0; c < nchunks; ++c, ++step) {
+            commit(step);
+            __syncthreads();      // this step's tiles are visible; every wave is done with the buffer the NEXT commit overwrites
+            if (step + 1 < nsteps) prefetch(step + 1);
+            const int t0 = c * XC_CH, cnt = min(XC_CH, a.nt - t0);
+            const __bf16* buf = kvbuf[step & 1] + lane * 8;
+            for (int tt = 0; tt < cnt; ++tt) {
+                const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(buf + tt * 2048);
+                const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(buf + tt * 2048 + 512);
+                const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(buf + tt * 2048 + 1024);
+                const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(buf + tt * 2048 + 1536);
+                // scores relative to the running maximum: the accumulator starts at -m (negm is refreshed only when m moves)
+                f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, negm, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q1, st, 0, 0, 0);
+                if (t0 + tt == a.nt - 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (!((tailmask >> r) & 1u)) st[r] = -1e30f;      // padding keys: exp2 gives exact zeros
+                    for (int r = 0; r < 16; ++r)
+                        if (!((tailmask >> r) & 1u)) st[r] = -1e30f;      // padding keys: exp2 gives exact zeros
+                }
+                float mx = st[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                // some query's maximum grew (rare after the first tiles; wave-uniform branch): move m, rescale
+                const bool first = (t0 + tt == 0);
+                if (first || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {
+                    const float delta = first ? mx : fmaxf(mx, 0.f);
+                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);      // o and lsum are still zero on the first tile
+                    m += delta;
+                    lsum *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        o[r] *= alpha;
+                        st[r] -= delta;
+                        negm[r] = -m;
+                    }
+                }
+                float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(st[r]), p1 = __builtin_amdgcn_exp2f(st[r + 1]);
+                    st[r] = p0;
+                    st[r + 1] = p1;
+                    ps0 += p0;
+                    ps1 += p1;
+                }
+                lsum += ps0 + ps1;
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, acc_frag(st, 0), o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, acc_frag(st, 1), o, 0, 0, 0);
             }
-            float mx = st[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-            m = mnew;
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[r] - mnew);
-                st[r] = p;
-                ps += p;
-            }
-            lsum = lsum * alpha + ps;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] *= alpha;
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, acc_frag(st, 0), o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, acc_frag(st, 1), o, 0, 0, 0);
         }
         lsum += __shfl_xor(lsum, 32);
         const float inv = 1.0f / lsum;                  // every query sees at least one real key (l >= 1)
@@ -197,10 +249,11 @@ extern "C" int vdmi_xattn_core(const void* q, int ldq, void* o, const void* kvpa
     a.l = l;
     a.nt = (l + 31) / 32;
     const long long gps = (rows_per_sample + 31) / 32;
-    if (gps * b > 0x7fffffffLL) return VDMI_E_SHAPE;
+    const long long bps = (gps + XC_WAVES - 1) / XC_WAVES;
+    if (gps > 0x7fffffffLL || bps * b > 0x7fffffffLL) return VDMI_E_SHAPE;
     a.groups_per_sample = (int)gps;
-    a.ngroups = (int)(gps * b);
-    hipLaunchKernelGGL(xattn_core_kernel, dim3((unsigned)((a.ngroups + 3) / 4)), dim3(256), 0,
+    a.blocks_per_sample = (int)bps;
+    hipLaunchKernelGGL(xattn_core_kernel, dim3((unsigned)(bps * b)), dim3(XC_WAVES * 64), 0,
                        static_cast<hipStream_t>(stream), a);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
