@@ -152,6 +152,8 @@ def resnet_block(sd: SD, p: str, x: Tensor, temb: Optional[Tensor]) -> Tensor:
         ss = e.chunk(2, dim=1)
     h = block(sd, p + ".block1", x, ss)
     h = block(sd, p + ".block2", h)
+    if (p + ".temporal_conv.weight") in sd:      # variant of version1diffusion.py:308,322: (3,1,1) conv over frames
+        h = F.conv3d(h, sd[p + ".temporal_conv.weight"], sd[p + ".temporal_conv.bias"], padding=(1, 0, 0))
     if (p + ".res_conv.weight") in sd:
         res = conv_1kk(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"], pad=0)
     else:
@@ -257,7 +259,19 @@ def spatial_attn_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg) -> Tensor:
 # --------------------------------------------------------------------------
 # A7  spatial linear attention (vdp.py:454-479), heads = attn_heads, dim_head 32
 # --------------------------------------------------------------------------
+def sta_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg) -> Tensor:
+    """Residual(PreNorm(SpatioTemporalAttention)) of version1diffusion.py:325-345, 431: full attention over the
+    f*h*w tokens of a sample, heads = attn_heads, dim_head 32."""
+    b, c, f, h, w = x.shape
+    y = layernorm_c(x, sd[p + ".fn.norm.gamma"])
+    tok = y.permute(0, 2, 3, 4, 1).reshape(b, 1, f * h * w, c)
+    o = attention_tokens(tok, sd[p + ".fn.fn.to_qkv.weight"], sd[p + ".fn.fn.to_out.weight"], cfg.attn_heads, 32, False, None)
+    return o.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3) + x
+
+
 def sla_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg) -> Tensor:
+    if sd[p + ".fn.fn.to_qkv.weight"].dim() == 2:      # the variant's Linear projection
+        return sta_residual(sd, p, x, cfg)
     b, c, f, h, w = x.shape
     heads, dh = cfg.attn_heads, 32
     y = layernorm_c(x, sd[p + ".fn.norm.gamma"])

@@ -365,6 +365,75 @@ def test_focus_present_mask_wide_channels_vs_oracle():
     assert rel_err(ref, plain) > 5 * MODEL_TOL
 
 
+def test_version1_variant_unet_vs_reference():
+    """version1diffusion.py's Unet3D (temporal conv in every ResnetBlock, full spatio-temporal attention,
+    max_distance 300) against that file's own outputs (tests/golden/v1_tiny.npz)."""
+    from video_diffusion_amd import version1 as V1
+    from oracle import weightgen
+    g = golden("v1_tiny")
+    m = V1.Unet3D(dim=32, dim_mults=(1, 2), channels=3)
+    m.load_state_dict(weightgen.fill_state_dict(m.state_dict(), 3))
+    m = m.to(dev()).eval()
+    x = inp("v1.x", tuple(int(v) for v in g["x_shape"])).to(dev())
+    t = g["t"].to(dev())
+    with torch.no_grad():
+        assert rel_err(m(x, t).cpu(), g["eps"]) < MODEL_TOL
+        assert rel_err(m(x, t, focus_present_mask=torch.tensor([False, True]).to(dev())).cpu(), g["eps_focus"]) < MODEL_TOL
+
+
+def test_version1_variant_wide_channels_vs_oracle():
+    """The variant's layers at a 256-channel level (split-channel convs, res_conv + temporal conv, unfused attention)."""
+    from video_diffusion_amd import version1 as V1
+    from oracle import weightgen
+    kw = dict(dim=64, dim_mults=(1, 4), channels=3)
+    m = V1.Unet3D(**kw)
+    m.load_state_dict(weightgen.fill_state_dict(m.state_dict(), 9))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = inp("v1w.x", (2, 3, 5, 8, 8))
+    t = torch.tensor([3, 700])
+    with torch.no_grad():
+        ref = O.unet3d_forward(sd, O.UnetCfg(dim=64, dim_mults=(1, 4), channels=3, max_distance=300), x, t)
+        out = m.to(dev()).eval()(x.to(dev()), t.to(dev()))
+    assert rel_err(out.cpu(), ref) < MODEL_TOL
+
+
+def test_version1_injection_sampling():
+    """p_sample with temporal_consistency_injection (version1diffusion.py:572-592, 656-706): before the step the first
+    overlap frames of x_t are the previous chunk's last frames noised to t; checked against the oracle's step on
+    the injected x_t, and sample() returns (samples, latents)."""
+    from video_diffusion_amd import VAE, version1 as V1
+    from oracle import weightgen
+    m = V1.Unet3D(dim=32, dim_mults=(1, 2), channels=4)
+    m.load_state_dict(weightgen.fill_state_dict(m.state_dict(), 3))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    vae = VAE(channels=3, latent_dim=4, base_dim=64)
+    vae.load_state_dict(weightgen.fill_state_dict(vae.state_dict(), 7))
+    T = 250
+    gd = V1.GaussianDiffusion(m, vae, image_size=64, num_frames=4, channels=3, timesteps=T, injection_steps=100).to(dev()).eval()
+    shape = (2, 4, 4, 8, 8)
+    prev = inp("v1.prev", shape).to(dev())
+    fn = V1.temporal_consistency_injection(gd, prev, overlap_frames=2, save_gif=False)
+    x = inp("v1.xt", shape).to(dev())
+    z = inp("v1.z", shape)
+    t = torch.full((2,), T - 1, dtype=torch.long)
+    torch.manual_seed(11)
+    x_inj = fn(x.clone(), t.to(dev()))
+    assert torch.equal(x_inj[:, :, 2:], x[:, :, 2:]) and not torch.equal(x_inj[:, :, :2], x[:, :, :2])
+    torch.manual_seed(11)
+    out = gd.p_sample(x.clone(), t.to(dev()), injection_fn=fn, noise=z.to(dev()))
+    cfg = O.UnetCfg(dim=32, dim_mults=(1, 2), channels=4, max_distance=300)
+    with torch.no_grad():
+        ref = O.p_sample_step(O.diffusion_buffers(T), x_inj.cpu(), t, O.unet3d_forward(sd, cfg, x_inj.cpu(), t), z)
+    assert rel_err(out.cpu(), ref) < 5e-2
+    late = torch.full((2,), T - 101, dtype=torch.long, device=dev())          # past the injection window
+    assert torch.equal(fn(x.clone(), late), x)
+    gd6 = V1.GaussianDiffusion(m, vae, image_size=64, num_frames=4, channels=3, timesteps=6, injection_steps=3).to(dev()).eval()
+    samples, latents = gd6.sample(batch_size=2, injection_fn=V1.temporal_consistency_injection(gd6, prev, 2, save_gif=False))
+    assert samples.shape == (2, 3, 4, 64, 64) and latents.shape == shape and torch.isfinite(samples).all()
+    with pytest.raises(NotImplementedError):
+        V1.temporal_consistency_guidance(gd6, prev, 2)(x, late)
+
+
 @pytest.mark.parametrize("scale", [1.0, 1.5])
 def test_frame_cond_sample_loop_vs_oracle(scale):
     """The frame-conditioned loop of sample() (doubled-batch guidance, cached keys/values) against the oracle's

@@ -179,3 +179,19 @@ def test_frame_conditioning_oracle_matches_reference_golden():
         assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], frame_cond=f, frame_keep=g["keep_mixed"]), g["eps_mixed"]) < 1e-5
         assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], focus=g["focus_mixed"]), g["eps_focus_mixed"]) < 1e-5
         assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], focus=torch.tensor([True, True])), g["eps_focus_all"]) < 1e-5
+
+
+def test_version1_variant_oracle_matches_reference_golden():
+    """The oracle's restatement of version1diffusion.py's Unet3D (temporal conv, spatio-temporal attention)
+    against that file's outputs (oracle/make_golden_v1.py)."""
+    import torch
+    from oracle import vdm_oracle as O, weightgen
+    from tests.helpers import golden, inp, rel_err
+    from video_diffusion_amd import version1 as V1
+    g = golden("v1_tiny")
+    sd = weightgen.fill_state_dict(V1.Unet3D(dim=32, dim_mults=(1, 2), channels=3).state_dict(), 3)
+    cfg = O.UnetCfg(dim=32, dim_mults=(1, 2), channels=3, max_distance=300)
+    x = inp("v1.x", tuple(int(v) for v in g["x_shape"]))
+    with torch.no_grad():
+        assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"]), g["eps"]) < 1e-5
+        assert rel_err(O.unet3d_forward(sd, cfg, x, g["t"], focus=torch.tensor([False, True])), g["eps_focus"]) < 1e-5

@@ -155,10 +155,14 @@ class GaussianDiffusion(nn.Module):
             seed, offset, torch.cuda.current_stream().cuda_stream), "vdmi_ddpm_step")
         return out
 
+    def _predict_noise(self, x, t, frame_cond_features=None):
+        # the call of reference vdp.py:978-983
+        return self.denoise_fn(x, t, frame_cond_features=frame_cond_features, null_frame_cond_prob=0.)
+
     @torch.inference_mode()
     def p_sample(self, x, t, frame_cond_features=None, clip_denoised=True, noise=None):
         # reference: vdp.py:973-1002
-        predicted_noise = self.denoise_fn(x, t, frame_cond_features=frame_cond_features, null_frame_cond_prob=0.)
+        predicted_noise = self._predict_noise(x, t, frame_cond_features)
         if clip_denoised and self.use_dynamic_thres:
             # per-sample quantile threshold (off by default): elementwise torch expressions
             x_recon = self._dynamic_clip(self.predict_start_from_noise(x, t=t, noise=predicted_noise))

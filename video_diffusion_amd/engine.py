@@ -216,11 +216,66 @@ class Plan:
             g1, s1, bstride = rb["gamma1"], None, 0
         hbuf = self._block(name + ".block1", (rb["w1"], rb["b1"]), srcs, h, w, g1, s1, bstride)
         cmid = rb["w1"].n
+        if "wt" in rb:
+            return self._resnet_temporal(name, rb, srcs, hbuf, cmid, h, w)
         if rb["wres"] is not None:
             res = ("conv", rb["wres"], rb["bres"], srcs)
         else:
             res = ("identity", srcs[0][0])
         return self._block(name + ".block2", (rb["w2"], rb["b2"]), [(hbuf, cmid)], h, w, rb["gamma2"], None, 0, res)
+
+    def _resnet_temporal(self, name, rb, srcs, hbuf, cmid, h, w) -> torch.Tensor:
+        """Tail of the variant ResnetBlock (reference version1diffusion.py:320-323): block2, then a (3,1,1)
+        convolution over frames, then + res_conv(x).  The temporal conv is a 3-tap pass over the rows seen as
+        B images of F x (h*w) pixels."""
+        frames, hw = self.B * self.F, h * w
+        h2 = self._block(name + ".block2", (rb["w2"], rb["b2"]), [(hbuf, cmid)], h, w, rb["gamma2"], None, 0, None)
+        if rb["wres"] is not None:
+            (r0, rc0), (r1, rc1) = srcs[0], (srcs[1] if len(srcs) > 1 else (None, 0))
+            res = self._buf(frames * hw, cmid)
+            b = self._base_args(frames, h, w, res, cmid, EPI_PLAIN)
+            _fill_pass(b.main, r0, rc0, r1, rc1, h, w, 1, [(0, 0)], rb["wres"].data)
+            b.bias = _ptr(rb["bres"])
+            b.tile_bn = rb["wres"].tile_bn
+            self._tapgemm(b, name + ".res")
+        else:
+            res = srcs[0][0]
+        y = self._buf(frames * hw, cmid)
+        a = self._base_args(self.B, self.F, hw, y, cmid, EPI_PLAIN)
+        _fill_pass(a.main, h2, cmid, None, 0, self.F, hw, 1, [(-1, 0), (0, 0), (1, 0)], rb["wt"].data)
+        a.bias = _ptr(rb["bt"])
+        a.has_res, a.res_identity, a.ld_res = 2, _ptr(res), cmid
+        self._tapgemm(a, name + ".temporal_conv")
+        return y
+
+    def _sta(self, name, st, x, c, h, w) -> torch.Tensor:
+        """Residual(PreNorm(SpatioTemporalAttention)) (reference version1diffusion.py:325-345): full softmax
+        attention over the F*h*w tokens of a sample; the keys/values are the layer's own projection, repacked
+        into the operand order of the cross-attention core."""
+        lib = _lib.lib()
+        frames, hw = self.B * self.F, h * w
+        rows, hid, n_tok = frames * hw, st["hid"], self.F * hw
+        heads = hid // 32
+        qkv = self._buf(rows, 3 * hid)
+        a = self._base_args(frames, h, w, qkv, 3 * hid, EPI_QKV_ATTN)
+        _fill_pass(a.main, x, c, None, 0, h, w, 1, [(0, 0)], st["wqkv"].data)
+        a.colsum = _ptr(st["wqkv"].colsum)
+        a.ln_eps, a.q_scale = 1e-5, st["scale"] * math.log2(math.e)
+        self._tapgemm(a, name + ".qkv")
+        kvp = torch.empty(lib.vdmi_xattn_kv_elems(1, self.B, n_tok, heads), device=self.device, dtype=torch.bfloat16)
+        self.keep.append(kvp)
+        self._add(lambda s, qkv=qkv: lib.vdmi_xattn_pack_kv(qkv.data_ptr() + 2 * hid, 3 * hid, kvp.data_ptr(), 1, self.B,
+                                                            n_tok, heads, s), None, name + ".pack_kv")
+        o = self._buf(rows, hid)
+        meta = {"kernel": "xattn_core", "flops": 4.0 * rows * hid * ((n_tok + 31) // 32) * 32, "bytes": 4.0 * rows * hid}
+        self._add(lambda s, qkv=qkv, o=o: lib.vdmi_xattn_core(qkv.data_ptr(), 3 * hid, o.data_ptr(), kvp.data_ptr(), self.B,
+                                                              n_tok, n_tok, heads, s), meta, name + ".core")
+        y = self._buf(rows, c)
+        b = self._base_args(frames, h, w, y, c, EPI_PLAIN)
+        _fill_pass(b.main, o, hid, None, 0, h, w, 1, [(0, 0)], st["wout"].data)
+        b.has_res, b.res_identity, b.ld_res = 2, _ptr(x), c
+        self._tapgemm(b, name + ".out")
+        return y
 
     def _attention(self, name, at, x, c, h, w, temporal: bool, focus: bool = False) -> torch.Tensor:
         """Residual(PreNorm(Attention)) over frames (temporal) or over the h*w positions (spatial).
@@ -446,7 +501,7 @@ class Plan:
             c = dims[i + 1]
             x = self._resnet(f"downs.{i}.1", L["rb1"], [(x, c)], h, w)
             if L["sla"] is not None:
-                x = self._sla(f"downs.{i}.2", L["sla"], x, c, h, w)
+                x = (self._sta if L["sla"].get("sta") else self._sla)(f"downs.{i}.2", L["sla"], x, c, h, w)
             x = self._attention(f"downs.{i}.3", L["tattn"], x, c, h, w, True, focus=True)
             if self.L:
                 x = self._cross_attention(f"frame_cross_attns_down.{i}", i, x, c, h, w)
@@ -473,7 +528,7 @@ class Plan:
             c = L["rb0"]["w1"].n
             x = self._resnet(f"ups.{i}.1", L["rb1"], [(x, c)], h, w)
             if L["sla"] is not None:
-                x = self._sla(f"ups.{i}.2", L["sla"], x, c, h, w)
+                x = (self._sta if L["sla"].get("sta") else self._sla)(f"ups.{i}.2", L["sla"], x, c, h, w)
             x = self._attention(f"ups.{i}.3", L["tattn"], x, c, h, w, True, focus=True)
             if self.L:
                 x = self._cross_attention(f"frame_cross_attns_up.{i}", nres + i, x, c, h, w)
@@ -552,6 +607,10 @@ class UnetEngine:
             d["bres"] = rb.res_conv.bias.detach().float().to(device).contiguous()
         else:
             d["wres"], d["bres"] = None, None
+        tc = getattr(rb, "temporal_conv", None)      # version1diffusion.py:308: (3,1,1) conv after block2
+        if tc is not None:
+            d["wt"] = PackedTaps(tc.weight.detach().float().cpu().reshape(cmid, cmid, 3), cmid, 0, EPI_PLAIN, device)
+            d["bt"] = tc.bias.detach().float().to(device).contiguous()
         if rb.mlp is not None:
             d["ss_off"] = stacked["half"]
             stacked["w"].append(rb.mlp[1].weight.detach().float().cpu())
@@ -624,9 +683,25 @@ class UnetEngine:
                 "scale": float(mods[0].fn.fn.scale),
                 "wkv": PackedTaps(wkv[:, :, None], wkv.shape[1], 0, EPI_PLAIN, device)}
 
+    def _pack_sta(self, res_mod, device):
+        """Residual(PreNorm(SpatioTemporalAttention)): q|k|v projection with the LayerNorm gamma folded in; the
+        out-projection's input columns follow the feature order vdmi_xattn_core writes."""
+        pre, st = res_mod.fn, res_mod.fn.fn
+        gamma = pre.norm.gamma.detach().float().reshape(-1).cpu()
+        wq = st.to_qkv.weight.detach().float().cpu() * gamma[None, :]
+        hid = st.to_out.weight.shape[1]
+        perm = torch.tensor([32 * hd + (r & 3) + 8 * (r >> 2) + 4 * hh
+                             for hd in range(hid // 32) for hh in (0, 1) for r in range(16)])
+        wo = st.to_out.weight.detach().float().cpu()[:, perm]
+        return {"sta": True, "hid": hid, "scale": float(st.scale),
+                "wqkv": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_ATTN, device, want_colsum=True),
+                "wout": PackedTaps(wo[:, :, None], hid, 0, EPI_PLAIN, device)}
+
     def _pack_sla(self, res_mod, device):
         pre = res_mod.fn
         sl = pre.fn
+        if not hasattr(sl, "to_qkv") or isinstance(sl.to_qkv, torch.nn.Linear):
+            return self._pack_sta(res_mod, device)
         gamma = pre.norm.gamma.detach().float().reshape(-1).cpu()
         wq = sl.to_qkv.weight.detach().float().cpu().reshape(sl.to_qkv.weight.shape[0], -1) * gamma[None, :]
         hid = sl.to_out.weight.shape[1]
