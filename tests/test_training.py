@@ -1,0 +1,165 @@
+"""CPU tests of the training path: the differentiable torch forward (autograd.py) against the reference's golden
+outputs, the Trainer loop (GIF dataset, EMA, checkpoint format), and data-parallel training over gloo (world 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from PIL import Image
+
+from oracle import weightgen
+from tests.helpers import TINY, TINY_COND, golden, inp, make_unet, rel_err
+
+
+def test_autograd_forward_matches_reference_golden():
+    from video_diffusion_amd import autograd as A, version1 as V1
+    g = golden("tiny_framecond")
+    m = make_unet(**TINY)
+    x = inp("fc.x", tuple(int(v) for v in g["x_shape"]))
+    with torch.no_grad():
+        assert rel_err(A.unet_forward(m, x, g["t"]), g["eps_plain"]) < 1e-5
+        assert rel_err(A.unet_forward(m, x, g["t"], frame_cond_features=g["features"]), g["eps_cond"]) < 1e-5
+        assert rel_err(A.unet_forward(m, x, g["t"], frame_cond_features=g["features"], null_frame_cond_prob=1.),
+                       g["eps_null"]) < 1e-5
+        assert rel_err(A.unet_forward(m, x, g["t"], focus_present_mask=g["focus_mixed"]), g["eps_focus_mixed"]) < 1e-5
+        assert rel_err(A.unet_forward(m, x, g["t"], prob_focus_present=1.), g["eps_focus_all"]) < 1e-5
+    gc = golden("tiny_cond")
+    mc = make_unet(salt=1, **TINY_COND)
+    xc = inp("tiny.x", (2, 3, 4, 12, 12))
+    with torch.no_grad():
+        assert rel_err(A.unet_forward(mc, xc, gc["t"], cond=gc["cond"]), gc["eps_cond"]) < 1e-5
+        assert rel_err(A.unet_forward(mc, xc, gc["t"], cond=gc["cond"], null_cond_prob=1.), gc["eps_null"]) < 1e-5
+    g1 = golden("v1_tiny")
+    m1 = V1.Unet3D(dim=32, dim_mults=(1, 2), channels=3)
+    m1.load_state_dict(weightgen.fill_state_dict(m1.state_dict(), 3))
+    with torch.no_grad():
+        assert rel_err(A.unet_forward(m1, inp("v1.x", tuple(int(v) for v in g1["x_shape"])), g1["t"]), g1["eps"]) < 1e-5
+
+
+def test_forward_needs_opt_in_for_gradients():
+    m = make_unet(**TINY)
+    x = inp("fc.x", (1, 3, 2, 8, 8)).requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        m(x, torch.tensor([3]))
+    m.train_backend = "torch-autograd"
+    out = m(x, torch.tensor([3]))
+    out.square().mean().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    assert m.init_conv.weight.grad is not None
+
+
+def _write_gifs(folder, n=4, frames=6, size=20):
+    os.makedirs(folder, exist_ok=True)
+    rng = np.random.RandomState(0)
+    for i in range(n):
+        imgs = [Image.fromarray(rng.randint(0, 255, (size, size + 4, 3), dtype=np.uint8)) for _ in range(frames)]
+        imgs[0].save(os.path.join(folder, f"v{i}.gif"), save_all=True, append_images=imgs[1:], duration=50, loop=0)
+
+
+def _build(folder, results, steps, seed=0):
+    from video_diffusion_amd import GaussianDiffusion, Trainer, Unet3D, VAE
+    from video_diffusion_amd.vae import FrameConditioningEncoder
+    torch.manual_seed(seed)
+    unet = Unet3D(dim=32, dim_mults=(1, 2), channels=4)
+    vae = VAE(channels=3, latent_dim=4, base_dim=32)
+    enc = FrameConditioningEncoder(4, 512, 2)
+    gd = GaussianDiffusion(unet, vae, image_size=16, num_frames=3, channels=3, timesteps=10, frame_cond_encoder=enc)
+    return Trainer(gd, folder, num_prev_frames=2, train_batch_size=2, train_num_steps=steps, gradient_accumulate_every=2,
+                   step_start_ema=1, update_ema_every=1, save_and_sample_every=10 ** 6, results_folder=results)
+
+
+def test_dataset_and_trainer_steps(tmp_path):
+    from video_diffusion_amd.trainer import Dataset
+    folder, results = str(tmp_path / "gifs"), str(tmp_path / "results")
+    _write_gifs(folder)
+    ds = Dataset(folder, 16, channels=3, num_frames=3, num_prev_frames=2)
+    item = ds[0]
+    assert item["current"].shape == (3, 3, 16, 16) and item["prev"].shape == (3, 2, 16, 16)
+    assert 0.0 <= float(item["current"].min()) and float(item["current"].max()) <= 1.0
+    tr = _build(folder, results, steps=2)
+    before = {k: v.clone() for k, v in tr.model.denoise_fn.state_dict().items()}
+    logs = []
+    tr.train(log_fn=logs.append)
+    assert tr.step == 2 and len(logs) == 2 and all(np.isfinite(l["loss"]) and np.isfinite(l["vae_loss"]) for l in logs)
+    after = tr.model.denoise_fn.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before)            # the optimizer moved the denoiser
+    assert tr.model.denoise_fn.frame_cross_attns_down[0].fn.fn.to_q.weight.grad is None   # zero_grad ran
+    # EMA follows the model with decay 0.995 after step_start_ema
+    k = "init_conv.weight"
+    ema, cur = tr.ema_model.denoise_fn.state_dict()[k], after[k]
+    assert not torch.equal(ema, cur) and rel_err(ema, cur) < 0.1
+    # checkpoint format of the reference: model-{milestone}.pt with step / model / ema / scaler / opt
+    tr.save(7)
+    data = torch.load(os.path.join(results, "model-7.pt"), weights_only=False)
+    assert set(data) == {"step", "model", "ema", "scaler", "opt"} and data["step"] == 2
+    tr2 = _build(folder, results, steps=2, seed=1)
+    tr2.load(-1)
+    assert tr2.step == 2 and torch.equal(tr2.model.denoise_fn.state_dict()[k], cur)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, folder, results, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    tr = _build(folder, results + str(rank), steps=2)       # same seed: identical initial weights on both ranks
+    assert tr.distributed
+    tr.train()
+    flat = torch.cat([p.detach().flatten() for p in tr.model.denoise_fn.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        q.put((bool(torch.equal(gathered[0], gathered[1])), float(flat.abs().sum())))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_keeps_replicas_identical(tmp_path):
+    folder, results = str(tmp_path / "gifs"), str(tmp_path / "results")
+    _write_gifs(folder)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, folder, results, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    same, norm = q.get(timeout=10)
+    assert same and np.isfinite(norm)       # different data shards, all-reduced gradients: replicas stay bit-identical
+
+
+@pytest.mark.gpu
+def test_trainer_on_gpu_trains_samples_and_saves(tmp_path):
+    """Two optimizer steps on the GPU (torch-autograd backward, HIP VAE inside the loss) followed by the
+    milestone: frame-conditioned and unconditional sampling of the EMA model on the HIP path, GIFs, checkpoint."""
+    from video_diffusion_amd import GaussianDiffusion, Trainer, Unet3D, VAE
+    from video_diffusion_amd.vae import FrameConditioningEncoder
+    folder, results = str(tmp_path / "gifs"), str(tmp_path / "results")
+    _write_gifs(folder, n=4, frames=6, size=36)
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    unet = Unet3D(dim=32, dim_mults=(1, 2), channels=4)
+    vae = VAE(channels=3, latent_dim=4, base_dim=64)
+    enc = FrameConditioningEncoder(4, 512, 2)
+    gd = GaussianDiffusion(unet, vae, image_size=32, num_frames=3, channels=3, timesteps=4, frame_cond_encoder=enc).to(dev)
+    gd.noise_source = "philox"
+    tr = Trainer(gd, folder, num_prev_frames=2, train_batch_size=2, train_num_steps=2, gradient_accumulate_every=1,
+                 step_start_ema=0, update_ema_every=1, save_and_sample_every=2, results_folder=results, num_sample_rows=2)
+    logs = []
+    tr.train(log_fn=logs.append)
+    assert len(logs) == 2 and all(np.isfinite(l["loss"]) for l in logs)
+    assert os.path.exists(os.path.join(results, "model-0.pt"))
+    assert os.path.exists(os.path.join(results, "0_cond_with_context.gif"))
+    assert os.path.exists(os.path.join(results, "0_unconditioned.gif"))
+    assert tr.ema_model.denoise_fn._engine is not None          # the milestone sampled through the HIP engine

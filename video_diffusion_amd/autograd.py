@@ -1,0 +1,207 @@
+"""Differentiable execution of Unet3D for training.
+
+The HIP kernels are forward-only.  The reference trains through PyTorch autograd (its Trainer,
+video_diffusion_pytorch/video_diffusion_pytorch.py:1414-1453, calls loss.backward() on torch ops); this module
+runs the same arithmetic as torch ops over the module's own parameters so that `loss.backward()`, the optimizer
+and DistributedDataParallel work unchanged.  It is never used for sampling: `Unet3D.forward` only comes here
+when gradients are required AND the owner opted in with `unet.train_backend = "torch-autograd"` (the Trainer
+does); otherwise a forward that needs gradients raises.  fp32 throughout, like the reference.
+
+Line references: vdp.py = video_diffusion_pytorch/video_diffusion_pytorch.py of the reference.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def _chan_layernorm(x, norm):
+    # vdp.py:380-389
+    var = torch.var(x, dim=1, unbiased=False, keepdim=True)
+    mean = torch.mean(x, dim=1, keepdim=True)
+    return (x - mean) / (var + norm.eps).sqrt() * norm.gamma
+
+
+def _rmsnorm(x, norm):
+    # vdp.py:391-398
+    return F.normalize(x, dim=1) * norm.scale * norm.gamma
+
+
+def _block(blk, x, scale_shift=None):
+    # vdp.py:410-427
+    x = _rmsnorm(blk.proj(x), blk.norm)
+    if scale_shift is not None:
+        scale, shift = scale_shift
+        x = x * (scale + 1) + shift
+    return F.silu(x)
+
+
+def _resnet(rb, x, temb):
+    # vdp.py:429-452; the (3,1,1) temporal conv of version1diffusion.py:308,322 when the block has one
+    ss = None
+    if rb.mlp is not None:
+        e = rb.mlp[1](F.silu(temb))
+        ss = e[:, :, None, None, None].chunk(2, dim=1)
+    h = _block(rb.block2, _block(rb.block1, x, ss))
+    if getattr(rb, "temporal_conv", None) is not None:
+        h = rb.temporal_conv(h)
+    return h + rb.res_conv(x)
+
+
+def _rotate(t, rot):
+    """t [..., n, d] with positions 0..n-1 on the second-to-last axis."""
+    n, d = t.shape[-2], t.shape[-1]
+    ang = torch.arange(n, device=t.device, dtype=torch.float32)[:, None] * rot.inv_freq.to(t.device)[None, :]
+    if getattr(rot, "convention", "half") == "interleaved":
+        ang = ang.repeat_interleave(2, dim=-1)
+        x1, x2 = t[..., 0::2], t[..., 1::2]
+        return t * ang.cos() + torch.stack((-x2, x1), dim=-1).reshape(t.shape) * ang.sin()
+    ang = torch.cat((ang, ang), dim=-1)              # video_diffusion_guidance.py:182-198
+    t1, t2 = t.chunk(2, dim=-1)
+    return t * ang.cos() + torch.cat((-t2, t1), dim=-1) * ang.sin()
+
+
+def _attention(att, x, pos_bias=None, focus=None):
+    """vdp.py:546-612 on x [b, g, n, c] (g groups of n tokens)."""
+    b, g, n, _ = x.shape
+    heads = att.heads
+    q, k, v = att.to_qkv(x).chunk(3, dim=-1)
+    q, k, v = (t.reshape(b, g, n, heads, -1).transpose(2, 3) for t in (q, k, v))     # [b, g, heads, n, d]
+    q = q * att.scale
+    if getattr(att, "rotary_emb", None) is not None:
+        q, k = _rotate(q, att.rotary_emb), _rotate(k, att.rotary_emb)
+    sim = q @ k.transpose(-1, -2)
+    if pos_bias is not None:
+        sim = sim + pos_bias
+    if focus is not None:
+        eye = torch.eye(n, device=x.device, dtype=torch.bool)
+        keep = eye.view(1, 1, 1, n, n) | ~focus.view(-1, 1, 1, 1, 1)
+        sim = sim.masked_fill(~keep, -torch.finfo(sim.dtype).max)
+    attn = (sim - sim.amax(dim=-1, keepdim=True).detach()).softmax(dim=-1)
+    out = (attn @ v).transpose(2, 3).reshape(b, g, n, -1)
+    return att.to_out(out)
+
+
+def _temporal(res, x, pos_bias, focus=None):
+    # Residual(PreNorm(EinopsToAndFrom('b c f h w', 'b (h w) f c', Attention))), vdp.py:636
+    b, c, f, h, w = x.shape
+    y = _chan_layernorm(x, res.fn.norm).permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
+    o = _attention(res.fn.fn.fn, y, pos_bias, focus)
+    return o.reshape(b, h, w, f, c).permute(0, 4, 3, 1, 2) + x
+
+
+def _spatial(res, x):
+    # mid_spatial_attn: 'b c f h w -> b f (h w) c', vdp.py:708-710
+    b, c, f, h, w = x.shape
+    y = _chan_layernorm(x, res.fn.norm).permute(0, 2, 3, 4, 1).reshape(b, f, h * w, c)
+    o = _attention(res.fn.fn.fn, y)
+    return o.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3) + x
+
+
+def _linear_attention(res, x):
+    sl = res.fn.fn
+    b, c, f, h, w = x.shape
+    y = _chan_layernorm(x, res.fn.norm)
+    if isinstance(sl.to_qkv, torch.nn.Linear):
+        # SpatioTemporalAttention, version1diffusion.py:325-345
+        tok = y.permute(0, 2, 3, 4, 1).reshape(b, 1, f * h * w, c)
+        return _attention(sl, tok).reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3) + x
+    # SpatialLinearAttention, vdp.py:454-479
+    yf = y.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    q, k, v = sl.to_qkv(yf).reshape(b * f, 3, sl.heads, -1, h * w).unbind(dim=1)
+    q = q.softmax(dim=-2) * sl.scale
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(b * f, -1, h, w)
+    out = sl.to_out(out)
+    return out.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4) + x
+
+
+def _cross_attention(res, x, ctx):
+    # Residual(PreNorm(CrossAttention)), vdp.py:480-528
+    ca = res.fn.fn
+    b, c, f, h, w = x.shape
+    tok = _chan_layernorm(x, res.fn.norm).permute(0, 2, 3, 4, 1).reshape(b, f * h * w, c)
+    q, k, v = ca.to_q(tok), ca.to_k(ctx), ca.to_v(ctx)
+    q, k, v = (t.reshape(b, t.shape[1], ca.heads, -1).transpose(1, 2) for t in (q, k, v))
+    attn = ((q @ k.transpose(-1, -2)) * ca.scale).softmax(dim=-1)
+    out = ca.to_out((attn @ v).transpose(1, 2).reshape(b, f * h * w, -1))
+    return out.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3) + x
+
+
+def _pos_bias(unet, nf, device):
+    # vdp.py:274-312: integer buckets from the library's host routine, gathered from the LIVE embedding weight
+    rpb = unet.time_rel_pos_bias
+    buckets = np.empty((nf, nf), dtype=np.int32)
+    _lib.check(_lib.lib().vdmi_relpos_buckets(nf, rpb.num_buckets, rpb.max_distance, buckets.ctypes.data),
+               "vdmi_relpos_buckets")
+    idx = torch.from_numpy(buckets.astype(np.int64)).to(device)
+    return rpb.relative_attention_bias.weight[idx].permute(2, 0, 1)
+
+
+def _mask(shape, prob, device):
+    # prob_mask_like, vdp.py:68-74
+    if prob == 1:
+        return torch.ones(shape, device=device, dtype=torch.bool)
+    if prob == 0:
+        return torch.zeros(shape, device=device, dtype=torch.bool)
+    return torch.zeros(shape, device=device).float().uniform_(0, 1) < prob
+
+
+def unet_forward(unet, x, time, cond=None, null_cond_prob=0., frame_cond_features=None, null_frame_cond_prob=0.,
+                 focus_present_mask=None, prob_focus_present=0.):
+    """Unet3D.forward (vdp.py:756-831) as differentiable torch ops over `unet`'s parameters."""
+    batch, device = x.shape[0], x.device
+    focus = focus_present_mask if focus_present_mask is not None else _mask((batch,), prob_focus_present, device)
+    focus = focus.to(device=device, dtype=torch.bool)
+    if not bool(focus.any()):
+        focus = None                                   # vdp.py:590: the mask is skipped when nothing is flagged
+    bias = _pos_bias(unet, x.shape[2], device)
+
+    x = unet.init_conv(x)
+    x = _temporal(unet.init_temporal_attn, x, bias)
+    r = x
+    half = unet.dim // 2
+    freq = torch.exp(torch.arange(half, device=device) * -(math.log(10000) / (half - 1)))
+    ang = time[:, None] * freq[None, :]
+    t = torch.cat((ang.sin(), ang.cos()), dim=-1)
+    t = unet.time_mlp[3](F.gelu(unet.time_mlp[1](t)))
+    if unet.has_cond:
+        m = _mask((batch,), null_cond_prob, device)
+        t = torch.cat((t, torch.where(m[:, None], unet.null_cond_emb, cond)), dim=-1)
+    ctx = None
+    if unet.has_frame_cross_attn and frame_cond_features is not None:
+        ctx = frame_cond_features
+        if null_frame_cond_prob > 0:
+            ctx = ctx * (1 - _mask((batch,), null_frame_cond_prob, device)[:, None, None].float())
+
+    skips = []
+    for i, (b1, b2, sattn, tattn, down) in enumerate(unet.downs):
+        x = _resnet(b2, _resnet(b1, x, t), t)
+        if unet.use_sparse_linear_attn:
+            x = _linear_attention(sattn, x)
+        x = _temporal(tattn, x, bias, focus)
+        if ctx is not None:
+            x = _cross_attention(unet.frame_cross_attns_down[i], x, ctx)
+        skips.append(x)
+        x = down(x)
+    x = _resnet(unet.mid_block1, x, t)
+    x = _spatial(unet.mid_spatial_attn, x)
+    x = _temporal(unet.mid_temporal_attn, x, bias, focus)
+    x = _resnet(unet.mid_block2, x, t)
+    for i, (b1, b2, sattn, tattn, up) in enumerate(unet.ups):
+        x = torch.cat((x, skips.pop()), dim=1)
+        x = _resnet(b2, _resnet(b1, x, t), t)
+        if unet.use_sparse_linear_attn:
+            x = _linear_attention(sattn, x)
+        x = _temporal(tattn, x, bias, focus)
+        if ctx is not None:
+            x = _cross_attention(unet.frame_cross_attns_up[i], x, ctx)
+        x = up(x)
+    x = torch.cat((x, r), dim=1)
+    return unet.final_conv[1](_resnet(unet.final_conv[0], x, None))

@@ -285,6 +285,19 @@ class Unet3D(nn.Module):
         self.final_conv = nn.Sequential(block_klass(dim * 2, dim), nn.Conv3d(dim, out_dim, 1))
 
         self._engine = None
+        # None: every forward runs on the HIP kernels (no gradients).  "torch-autograd": a forward that needs
+        # gradients runs as differentiable torch ops instead (training only; see autograd.py).
+        self.train_backend = None
+
+    def __deepcopy__(self, memo):
+        # copies (the Trainer's EMA model) start without the packed-weight cache of the original
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == "_engine" else copy.deepcopy(v, memo)
+        return new
 
     # -- execution ---------------------------------------------------------------
     def engine(self):
@@ -320,8 +333,18 @@ class Unet3D(nn.Module):
     ):
         # reference: vdp.py:756-831
         assert not (self.has_cond and not exists(cond)), 'cond must be passed in if cond_dim specified'
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
-            raise NotImplementedError("the HIP denoiser is forward-only; backward is not built yet")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if self.train_backend == "torch-autograd":
+                # training: the same arithmetic as differentiable torch ops (autograd.py), as the reference trains
+                from . import autograd
+                return autograd.unet_forward(self, x, time, cond=cond, null_cond_prob=null_cond_prob,
+                                             frame_cond_features=frame_cond_features,
+                                             null_frame_cond_prob=null_frame_cond_prob,
+                                             focus_present_mask=focus_present_mask, prob_focus_present=prob_focus_present)
+            if x.requires_grad:
+                raise NotImplementedError(
+                    "the HIP denoiser is forward-only; set unet.train_backend = 'torch-autograd' (the Trainer does) "
+                    "to run a differentiable forward through PyTorch ops")
         return self.engine().forward(x, time, cond=cond, null_cond_prob=null_cond_prob,
                                      frame_cond_features=frame_cond_features,
                                      null_frame_cond_prob=null_frame_cond_prob,
