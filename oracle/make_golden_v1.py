@@ -20,10 +20,15 @@ from oracle.make_golden import save  # noqa: E402
 
 KW = dict(dim=32, dim_mults=(1, 2), channels=3)
 X_SHAPE = (2, 3, 4, 12, 12)
+G_SHAPE = (2, 4, 3, 4, 4)
 
 
-@torch.no_grad()
 def main():
+  with torch.no_grad():
+    _main()
+
+
+def _main():
     torch.set_num_threads(8)
     ref_import.load_reference()                       # installs the import stubs and the path
     import video_diffusion_guidance as vdg
@@ -34,8 +39,20 @@ def main():
     m.eval()
     x = weightgen.synthetic_input("v1.x", X_SHAPE)
     t = torch.tensor([4, 871])
+    # reconstruction guidance (version1diffusion.py:707-747) on a 4-channel latent model + the file's VAE
+    m4 = v1.Unet3D(dim=32, dim_mults=(1, 2), channels=4)
+    m4.load_state_dict(weightgen.fill_state_dict(m4.state_dict(), 3))
+    vae = v1.VAE(channels=3, latent_dim=4, base_dim=64)
+    vae.load_state_dict(weightgen.fill_state_dict(vae.state_dict(), 7))
+    gd = v1.GaussianDiffusion(m4.eval(), vae.eval(), image_size=32, num_frames=3, channels=3, timesteps=250)
+    z_t = weightgen.synthetic_input("v1.zt", G_SHAPE)
+    prev = weightgen.synthetic_input("v1.prevpix", (2, 3, 2, 32, 32)).mul(0.25).add(0.5).clamp(0, 1)
+    tg = torch.tensor([200, 40])
+    with torch.enable_grad():
+        guid = v1.temporal_consistency_guidance(gd, prev, 2, w_r=3.0)(z_t, tg)
     save("v1_tiny", x_shape=torch.tensor(X_SHAPE), t=t, eps=m(x, t),
-         eps_focus=m(x, t, focus_present_mask=torch.tensor([False, True])))
+         eps_focus=m(x, t, focus_present_mask=torch.tensor([False, True])),
+         g_shape=torch.tensor(G_SHAPE), g_t=tg, guidance=guid)
 
 
 if __name__ == "__main__":

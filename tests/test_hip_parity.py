@@ -430,8 +430,6 @@ def test_version1_injection_sampling():
     gd6 = V1.GaussianDiffusion(m, vae, image_size=64, num_frames=4, channels=3, timesteps=6, injection_steps=3).to(dev()).eval()
     samples, latents = gd6.sample(batch_size=2, injection_fn=V1.temporal_consistency_injection(gd6, prev, 2, save_gif=False))
     assert samples.shape == (2, 3, 4, 64, 64) and latents.shape == shape and torch.isfinite(samples).all()
-    with pytest.raises(NotImplementedError):
-        V1.temporal_consistency_guidance(gd6, prev, 2)(x, late)
 
 
 @pytest.mark.parametrize("scale", [1.0, 1.5])

@@ -11,7 +11,8 @@ def _use_hip(module, x):
     """GPU tensors outside autograd run on the HIP launch plans (vae_engine.py; they raise if libvdmi.so is
     missing).  CPU tensors and training (the VAE's own trainer, the frame encoder inside p_losses) keep the
     torch layers the parameters live in."""
-    return x.is_cuda and not (torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()))
+    return x.is_cuda and not (torch.is_grad_enabled() and
+                              (x.requires_grad or any(p.requires_grad for p in module.parameters())))
 
 
 def _engine(module, cls_name):

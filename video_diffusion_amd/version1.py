@@ -12,7 +12,7 @@ Class names, constructor signatures and state-dict keys follow that file.  The t
 3-tap vdmi_tapgemm over the (frame, position) view of the rows; the full attention reuses the
 cross-attention core (vdmi_xattn_pack_kv / vdmi_xattn_core) with the layer's own keys and values.
 Reconstruction guidance (`temporal_consistency_guidance`, :707-747) differentiates through the denoiser and
-the VAE decoder, which the forward-only HIP path cannot do; it raises when called.
+the VAE decoder; that derivative is taken with PyTorch autograd ops (the HIP kernels are forward-only).
 """
 from __future__ import annotations
 
@@ -71,17 +71,17 @@ class GaussianDiffusion(_diffusion.GaussianDiffusion):
                          dynamic_thres_percentile=dynamic_thres_percentile, latent_scale=latent_scale)
         self.injection_steps = injection_steps
 
-    @torch.inference_mode()
     def p_sample(self, x, t, clip_denoised=True, guidance_fn=None, guidance_scale=1.0, injection_fn=None, noise=None):
-        # :572-592 — injection wins over guidance; both act on x_t before the denoiser sees it
-        if injection_fn is not None:
-            x = injection_fn(x, t)
-        elif guidance_fn is not None:
-            grad = guidance_fn(x, t)
-            x = x + guidance_scale * extract(self.betas, t, x.shape) * grad
+        # :572-592 — injection wins over guidance; both act on x_t before the denoiser sees it.  Not under
+        # inference_mode: a guidance_fn differentiates with respect to x_t.
+        with torch.no_grad():
+            if injection_fn is not None:
+                x = injection_fn(x.clone(), t)
+            elif guidance_fn is not None:
+                grad = guidance_fn(x, t)
+                x = x + guidance_scale * extract(self.betas, t, x.shape) * grad
         return super().p_sample(x, t, clip_denoised=clip_denoised, noise=noise)
 
-    @torch.inference_mode()
     def p_sample_loop(self, shape, guidance_fn=None, guidance_scale=1.0, injection_fn=None, x_T=None, noises=None):
         # :594-608
         if guidance_fn is None and injection_fn is None:
@@ -154,12 +154,30 @@ def temporal_consistency_injection(model, prev_latents, overlap_frames, save_gif
 
 
 def temporal_consistency_guidance(model, prev_frames, overlap_frames, w_r=1.0):
-    """version1diffusion.py:707-747 needs d(reconstruction loss)/d(z_t) through the denoiser and the VAE decoder."""
+    """version1diffusion.py:707-747: -w_r * alphas_cumprod_t * d/dz_t mse(decode(x0_hat(z_t))[first frames], prev_frames).
+    The derivative runs through the denoiser and the VAE decoder as PyTorch autograd ops (autograd.py and the
+    VAE's torch layers: the HIP kernels are forward-only); the step that follows runs on the HIP kernels."""
+    for param in model.vae.decoder.parameters():
+        param.requires_grad = False
 
     def guidance_fn(z_t, t):
         if prev_frames is None:
             return torch.zeros_like(z_t)
-        raise NotImplementedError("reconstruction guidance differentiates through Unet3D and the VAE decoder; "
-                                  "the MI355X path is forward-only (use temporal_consistency_injection)")
+        fn = model.denoise_fn
+        z = z_t.detach().clone().requires_grad_(True)
+        backend = getattr(fn, "train_backend", None)
+        with torch.enable_grad():
+            if hasattr(fn, "train_backend"):
+                fn.train_backend = "torch-autograd"
+            try:
+                x_recon = model.predict_start_from_noise(z, t, fn(z, t))
+                overlap = x_recon[:, :, :overlap_frames] if x_recon.dim() == 5 else x_recon
+                pixels = (model.vae.decode(overlap / model.latent_scale).clamp(-1, 1) + 1) / 2
+                loss = nn.functional.mse_loss(pixels, prev_frames, reduction='mean')
+                grad = torch.autograd.grad(loss, z)[0]
+            finally:
+                if hasattr(fn, "train_backend"):
+                    fn.train_backend = backend
+        return (-w_r * extract(model.alphas_cumprod, t, z_t.shape) * grad).detach()
 
     return guidance_fn
