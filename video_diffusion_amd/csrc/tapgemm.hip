@@ -59,6 +59,7 @@ struct PassDev {
     // frame stacking: a tile covers `fstack` whole frames of fs_rows tile rows each (images smaller than
     // the pixel tile); every frame has its own haloed band of `phf` patch rows.  fstack == 1: off.
     int fstack, fs_rows, phf, nframes;
+    float inv_pw, inv_phf;   // 1/pw, 1/phf: row -> (y, x) of a patch row without integer division
     // phases (main pass of a PLAIN launch): the taps are `phases` equal groups, each an independent
     // convolution with its own weight set and output parity; blockIdx.z enumerates (frame group, phase)
     int phases;
@@ -159,14 +160,16 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     // source pixel of each patch piece this thread stages (-1: padding) -- the same for every chunk
     int ppix[STATS ? 1 : LB];
     if constexpr (!STATS) {
-        int ry = r0 / g.pw, rx = r0 - ry * g.pw;
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
+            // patch row -> (ry, rx): (r + 0.5) / pw is never within 0.5 / pw of an integer, far above fp32 rounding here
+            const int r = r0 + u * RSTEP;
+            const int ry = (int)(((float)r + 0.5f) * g.inv_pw), rx = r - ry * g.pw;
             int iy = iy0 + ry, fr = frame;
             const int ix = ix0 + rx;
-            bool ok = r0 + u * RSTEP < nrows;
+            bool ok = r < nrows;
             if (g.fstack > 1) {
-                const int fi = ry / g.phf;
+                const int fi = (int)(((float)ry + 0.5f) * g.inv_phf);
                 iy = g.min_dy + ry - fi * g.phf;
                 fr = frame + fi;
                 ok = ok && fr < g.nframes;
@@ -181,8 +184,6 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
             } else {
                 ppix[u] = ok ? (fr * g.in_h + iy) * g.in_w + ix : -1;
             }
-            rx += RSTEP;
-            while (rx >= g.pw) { rx -= g.pw; ++ry; }
         }
     }
     auto patch_prefetch = [&](int c) {
@@ -867,9 +868,13 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
             k.main.ph = fstack * k.main.phf;
             frames = (frames + fstack - 1) / fstack;   // grid.z: frame groups
         }
+        k.main.inv_pw = 1.0f / (float)k.main.pw;
+        k.main.inv_phf = k.main.phf > 0 ? 1.0f / (float)k.main.phf : 0.f;
         if (A.has_res == 1) {
             k.res = res_base;
             finish_pass(A.res, &k.res, th, tw);
+            k.res.inv_pw = 1.0f / (float)k.res.pw;
+            k.res.inv_phf = 0.f;
         }
         k.has_res = A.has_res;
         k.res_identity = static_cast<const __bf16*>(A.res_identity);
