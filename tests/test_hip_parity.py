@@ -733,6 +733,31 @@ def test_batch_independence_full_size():
     assert torch.equal(full, torch.cat([a, b]))
 
 
+@pytest.mark.parametrize("name,kw,shape", [
+    ("dim96", dict(dim=96, dim_mults=(1, 2), channels=3), (2, 3, 4, 12, 20)),                 # widths that are not powers of two
+    ("F33", dict(dim=32, dim_mults=(1, 2), channels=3), (1, 3, 33, 8, 8)),                   # more frames than a fused group holds
+    ("F1", dict(dim=32, dim_mults=(1, 2), channels=3), (2, 3, 1, 8, 8)),                     # single frame
+    ("odd_hw", dict(dim=32, dim_mults=(1, 2), channels=1), (3, 1, 5, 6, 10)),                # ragged tiles, odd batch
+    ("three_levels_b1", dict(dim=32, dim_mults=(1, 2, 4), channels=4), (1, 4, 3, 12, 12)),
+    ("no_sla", dict(dim=32, dim_mults=(1, 2), channels=3, use_sparse_linear_attn=False), (2, 3, 4, 8, 8)),
+    ("k5_out6", dict(dim=32, dim_mults=(1, 2), channels=3, init_kernel_size=5, out_dim=6), (2, 3, 4, 8, 8)),
+])
+def test_unusual_shapes_vs_oracle(name, kw, shape):
+    """Constructor options and input shapes off the benchmark path, against the (reference-pinned) oracle."""
+    m = make_unet(salt=2, **kw)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    cfg = O.UnetCfg(dim=kw["dim"], dim_mults=kw["dim_mults"], channels=kw["channels"],
+                    init_kernel_size=kw.get("init_kernel_size", 7), out_dim=kw.get("out_dim"),
+                    use_sparse_linear_attn=kw.get("use_sparse_linear_attn", True))
+    x = inp("edge." + name, shape)
+    t = torch.randint(0, 1000, (shape[0],), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = O.unet3d_forward(sd, cfg, x, t)
+        out = m.to(dev())(x.to(dev()), t.to(dev())).cpu()
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < MODEL_TOL
+
+
 def test_errors_are_loud():
     m = make_unet(**TINY)
     with pytest.raises(Exception):
