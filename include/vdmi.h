@@ -182,6 +182,19 @@ int vdmi_xattn_core(const void* q, int ldq, void* o, const void* kvpack_layer, i
 size_t vdmi_groupnorm_workspace_bytes(int nsamples, int64_t rows_per_sample, int c);      /* HOST */
 int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
                         const float* gamma, const float* beta, float eps, void* workspace, vdmi_stream stream);
+/* The general form: act 0 = none, 1 = SiLU; then an optional per-(sample, channel) affine
+ * y * post_gain[b][ch] + post_shift[b][ch] (row stride post_bstride; the time-embedding scale + 1 / shift of
+ * video_diffusion_guidance.py:378-382), then an optional residual add of bf16 rows [..][ld_res]. */
+int vdmi_groupnorm(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
+                   const float* gamma, const float* beta, float eps, int act, const float* post_gain,
+                   const float* post_shift, int64_t post_bstride, const void* residual, int ld_res, void* workspace,
+                   vdmi_stream stream);
+
+/* Depthwise temporal convolution Conv3d(c, c, (k,1,1), padding (k/2,0,0), groups=c) of
+ * video_diffusion_guidance.py:324-325 over channels-last bf16 rows [b*f*hw][ldx] -> [b*f*hw][ldo] (the first c
+ * columns of each); w: float [c][k], bias: float [c] or NULL; k odd. */
+int vdmi_temporal_dwconv(const void* x, int ldx, void* out, int ldo, int b, int f, int64_t hw, int c, int k,
+                         const float* w, const float* bias, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Softmax attention core over a small token axis (temporal attention over frames with

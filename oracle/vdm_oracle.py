@@ -401,6 +401,86 @@ def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
     return conv_1kk(x, sd["final_conv.1.weight"], sd["final_conv.1.bias"], pad=0)
 
 
+# --------------------------------------------------------------------------
+# N3  the video_diffusion_guidance.py variant of the denoiser (:319-388, :390-459, :515-635): factorised
+# temporal (depthwise) -> spatial blocks with GroupNorm(8), temporal then per-frame spatial softmax attention
+# --------------------------------------------------------------------------
+def _g_ts_block(sd: SD, p: str, x: Tensor) -> Tensor:
+    k = sd[p + ".temporal_conv.weight"].shape[2]
+    h = F.conv3d(x, sd[p + ".temporal_conv.weight"], sd[p + ".temporal_conv.bias"], padding=(k // 2, 0, 0), groups=x.shape[1])
+    h = F.silu(F.group_norm(h, 8, sd[p + ".temporal_norm.weight"], sd[p + ".temporal_norm.bias"], eps=1e-5))
+    h = conv_1kk(h, sd[p + ".spatial_conv.weight"], sd[p + ".spatial_conv.bias"])
+    return F.silu(F.group_norm(h, 8, sd[p + ".spatial_norm.weight"], sd[p + ".spatial_norm.bias"], eps=1e-5))
+
+
+def _g_resnet(sd: SD, p: str, x: Tensor, temb: Optional[Tensor]) -> Tensor:
+    res = x
+    if (p + ".res_conv.0.weight") in sd:
+        w = sd[p + ".res_conv.0.weight"]
+        res = F.conv3d(x, w, sd[p + ".res_conv.0.bias"], padding=(w.shape[2] // 2, 0, 0))
+        res = F.group_norm(res, 8, sd[p + ".res_conv.1.weight"], sd[p + ".res_conv.1.bias"], eps=1e-5)
+    h = _g_ts_block(sd, p + ".ts_block1", x)
+    if (p + ".mlp.1.weight") in sd and temb is not None:
+        e = F.linear(F.silu(temb), sd[p + ".mlp.1.weight"], sd[p + ".mlp.1.bias"])[:, :, None, None, None]
+        scale, shift = e.chunk(2, dim=1)
+        h = h * (scale + 1) + shift
+    return _g_ts_block(sd, p + ".ts_block2", h) + res
+
+
+def _g_temporal(sd: SD, p: str, x: Tensor, cfg: UnetCfg, pos_bias: Tensor) -> Tensor:
+    b, c, f, h, w = x.shape
+    y = layernorm_c(x, sd[p + ".fn.norm.gamma"])
+    tok = y.permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
+    o = attention_tokens(tok, sd[p + ".fn.fn.to_qkv.weight"], sd[p + ".fn.fn.to_out.weight"],
+                         cfg.attn_heads, cfg.attn_dim_head, cfg.rotary, pos_bias)
+    return o.reshape(b, h, w, f, c).permute(0, 4, 3, 1, 2) + x
+
+
+def _g_spatial(sd: SD, p: str, x: Tensor, cfg: UnetCfg) -> Tensor:
+    b, c, f, h, w = x.shape
+    y = layernorm_c(x, sd[p + ".fn.norm.gamma"])
+    tok = y.permute(0, 2, 3, 4, 1).reshape(b, f, h * w, c)
+    o = attention_tokens(tok, sd[p + ".fn.fn.to_qkv.weight"], sd[p + ".fn.fn.to_out.weight"],
+                         cfg.attn_heads, cfg.attn_dim_head, False, None)
+    return o.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3) + x
+
+
+def unet3d_guidance_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor) -> Tensor:
+    """Unet3D.forward of video_diffusion_guidance.py:596-635 (cfg.max_distance must be 300, :526)."""
+    bias = relpos_bias(sd["time_rel_pos_bias.relative_attention_bias.weight"], x.shape[2], cfg.num_buckets, cfg.max_distance)
+    x = conv_1kk(x, sd["init_conv.weight"], sd["init_conv.bias"], pad=cfg.init_kernel_size // 2)
+    x = _g_temporal(sd, "init_temporal_attn", x, cfg, bias)
+    r = x
+    t = time_mlp(sd, time, cfg.dim)
+    skips = []
+    nres = len(cfg.in_out)
+    for i in range(nres):
+        p = f"downs.{i}"
+        x = _g_resnet(sd, p + ".0", x, t)
+        x = _g_resnet(sd, p + ".1", x, t)
+        x = _g_temporal(sd, p + ".2", x, cfg, bias)
+        x = _g_spatial(sd, p + ".3", x, cfg)
+        skips.append(x)
+        if i < nres - 1:
+            x = downsample(sd, p + ".4", x)
+    x = _g_resnet(sd, "mid_block1", x, t)
+    x = _g_temporal(sd, "mid_temporal_attn", x, cfg, bias)
+    x = _g_spatial(sd, "mid_spatial_attn", x, cfg)
+    x = _g_resnet(sd, "mid_block2", x, t)
+    for i in range(nres):
+        p = f"ups.{i}"
+        x = torch.cat((x, skips.pop()), dim=1)
+        x = _g_resnet(sd, p + ".0", x, t)
+        x = _g_resnet(sd, p + ".1", x, t)
+        x = _g_temporal(sd, p + ".2", x, cfg, bias)
+        x = _g_spatial(sd, p + ".3", x, cfg)
+        if i < nres - 1:
+            x = upsample(sd, p + ".4", x)
+    x = torch.cat((x, r), dim=1)
+    x = _g_resnet(sd, "final_conv.0", x, None)      # nn.Sequential calls it without the time embedding (:635)
+    return conv_1kk(x, sd["final_conv.1.weight"], sd["final_conv.1.bias"], pad=0)
+
+
 def unet3d_forward_cfg(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor, cond: Tensor,
                        cond_scale: float = 2.0) -> Tensor:
     """forward_with_cond_scale, text-CFG branch only (vdp.py:731-754)."""

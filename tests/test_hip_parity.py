@@ -432,6 +432,83 @@ def test_version1_injection_sampling():
     assert samples.shape == (2, 3, 4, 64, 64) and latents.shape == shape and torch.isfinite(samples).all()
 
 
+def test_guidance_variant_unet_vs_reference():
+    """video_diffusion_guidance.py's Unet3D (depthwise temporal conv + GroupNorm blocks, temporal then per-frame
+    spatial attention) against that file's own output (tests/golden/guidance_tiny.npz)."""
+    from video_diffusion_amd import guidance_variant as GV
+    from oracle import weightgen
+    g = golden("guidance_tiny")
+    m = GV.Unet3D(dim=64, dim_mults=(1, 2), channels=4)
+    m.load_state_dict(weightgen.fill_state_dict(m.state_dict(), 4))
+    m = m.to(dev()).eval()
+    x = inp("g.x", tuple(int(v) for v in g["x_shape"])).to(dev())
+    with torch.no_grad():
+        out = m(x, g["t"].to(dev()))
+    assert rel_err(out.cpu(), g["eps"]) < MODEL_TOL
+
+
+def test_guidance_variant_larger_vs_oracle():
+    """The same variant with three levels (256-channel bottleneck: unfused attention, split-channel convs), odd batch."""
+    from video_diffusion_amd import guidance_variant as GV
+    from oracle import weightgen
+    kw = dict(dim=64, dim_mults=(1, 2, 4), channels=4)
+    m = GV.Unet3D(**kw)
+    m.load_state_dict(weightgen.fill_state_dict(m.state_dict(), 6))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = inp("g2.x", (3, 4, 5, 8, 12))
+    t = torch.tensor([0, 400, 999])
+    with torch.no_grad():
+        ref = O.unet3d_guidance_forward(sd, O.UnetCfg(dim=64, dim_mults=(1, 2, 4), channels=4, max_distance=300), x, t)
+        out = m.to(dev()).eval()(x.to(dev()), t.to(dev()))
+    assert rel_err(out.cpu(), ref) < MODEL_TOL
+
+
+@pytest.mark.parametrize("c,k,f,hw,nb", [(64, 3, 5, 37, 2), (128, 5, 4, 16, 1), (256, 3, 1, 10, 3)])
+def test_temporal_dwconv_vs_torch(c, k, f, hw, nb):
+    """vdmi_temporal_dwconv against torch's grouped Conv3d on the same bf16 rows."""
+    from video_diffusion_amd import _lib
+    lib = _lib.lib()
+    x = inp(f"dw.x{c}", (nb * f * hw, c)).to(torch.bfloat16)
+    w = (0.5 * inp(f"dw.w{c}", (c, k))).contiguous()
+    b = (0.1 * inp(f"dw.b{c}", (c,))).contiguous()
+    xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())
+    out = torch.empty_like(xd)
+    _lib.check(lib.vdmi_temporal_dwconv(xd.data_ptr(), c, out.data_ptr(), c, nb, f, hw, c, k, wd.data_ptr(), bd.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    x5 = x.float().reshape(nb, f, hw, 1, c).permute(0, 4, 1, 2, 3)
+    ref = torch.nn.functional.conv3d(x5, w.reshape(c, 1, k, 1, 1), b, padding=(k // 2, 0, 0), groups=c)
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(nb * f * hw, c)
+    assert rel_err(out.float().cpu(), ref) < 4e-3
+
+
+def test_groupnorm_general_form():
+    """vdmi_groupnorm without activation, with the per-sample affine and the residual rows."""
+    from video_diffusion_amd import _lib
+    lib = _lib.lib()
+    c, groups, rows, nb = 128, 8, 600, 2
+    x = (inp("gn2.x", (nb * rows, c), scale=2.0) + 0.3).to(torch.bfloat16)
+    res = inp("gn2.r", (nb * rows, c)).to(torch.bfloat16)
+    gamma, beta = (1.0 + 0.3 * inp("gn2.g", (c,))).contiguous(), (0.2 * inp("gn2.b", (c,))).contiguous()
+    pg, ps = (1.0 + 0.5 * inp("gn2.pg", (nb, c + 8))).contiguous(), inp("gn2.ps", (nb, c + 8)).contiguous()
+    d = dev()
+    xd, rd, gd_, bd, pgd, psd = x.to(d), res.to(d), gamma.to(d), beta.to(d), pg.to(d), ps.to(d)
+    ws = torch.empty(lib.vdmi_groupnorm_workspace_bytes(nb, rows, c), device=d, dtype=torch.uint8)
+    s = torch.cuda.current_stream().cuda_stream
+    xr = x.float().reshape(nb, rows, c).permute(0, 2, 1)
+    gn = torch.nn.functional.group_norm(xr, groups, gamma, beta, 1e-5).permute(0, 2, 1)
+    out = torch.empty_like(xd)
+    _lib.check(lib.vdmi_groupnorm(xd.data_ptr(), out.data_ptr(), nb, rows, c, groups, gd_.data_ptr(), bd.data_ptr(), 1e-5, 0,
+                                  None, None, 0, None, 0, ws.data_ptr(), s))
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu().reshape(nb, rows, c), gn) < 4e-3
+    _lib.check(lib.vdmi_groupnorm(xd.data_ptr(), out.data_ptr(), nb, rows, c, groups, gd_.data_ptr(), bd.data_ptr(), 1e-5, 1,
+                                  pgd.data_ptr(), psd.data_ptr(), c + 8, rd.data_ptr(), c, ws.data_ptr(), s))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.silu(gn) * pg[:, None, :c] + ps[:, None, :c] + res.float().reshape(nb, rows, c)
+    assert rel_err(out.float().cpu().reshape(nb, rows, c), ref) < 4e-3
+
+
 @pytest.mark.parametrize("scale", [1.0, 1.5])
 def test_frame_cond_sample_loop_vs_oracle(scale):
     """The frame-conditioned loop of sample() (doubled-batch guidance, cached keys/values) against the oracle's

@@ -100,6 +100,11 @@ _SIGNATURES = {
     "vdmi_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
     "vdmi_groupnorm_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "vdmi_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p]),
+    "vdmi_temporal_dwconv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdmi_xattn_kv_elems": (C.c_size_t, [C.c_int] * 4),
     "vdmi_xattn_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vdmi_xattn_pack_kv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

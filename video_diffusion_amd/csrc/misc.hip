@@ -656,7 +656,10 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const __bf16* __re
                                                               long long rows_per_sample, int c, int groups,
                                                               const float* __restrict__ part, int nsplit,
                                                               const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float eps) {
+                                                              const float* __restrict__ beta, float eps, int act,
+                                                              const float* __restrict__ post_gain,
+                                                              const float* __restrict__ post_shift, long long post_bstride,
+                                                              const __bf16* __restrict__ res, int ld_res) {
     __shared__ float mean_s[256], rstd_s[256];
     const int ppr = c / 8, rpi = 256 / ppr, ppg = ppr / groups;      // pieces per group
     const int tid = threadIdx.x, piece = tid % ppr, r0 = tid / ppr;
@@ -686,13 +689,57 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const __bf16* __re
     const long long per = (rows_per_sample + gridDim.x - 1) / gridDim.x;
     const long long lo = blockIdx.x * per, hi = lo + per < rows_per_sample ? lo + per : rows_per_sample;
     const long long base = (long long)b * rows_per_sample * c;
+    // optional per-(sample, channel) affine after the activation (time-embedding scale / shift), optional residual rows
+    float pg[8], ps[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        pg[e] = post_gain ? post_gain[b * post_bstride + piece * 8 + e] : 1.f;
+        ps[e] = post_shift ? post_shift[b * post_bstride + piece * 8 + e] : 0.f;
+    }
+    const long long row0 = (long long)b * rows_per_sample;
     for (long long r = lo + r0; r < hi; r += rpi) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + base + r * c + piece * 8);
+        bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (res) rv = *reinterpret_cast<const bf16x8*>(res + (row0 + r) * ld_res + piece * 8);
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(fmaf((float)v[e], ga[e], be[e])));
+        for (int e = 0; e < 8; ++e) {
+            float y = fmaf((float)v[e], ga[e], be[e]);
+            if (act) y = silu_f(y);
+            o[e] = f2bf(fmaf(y, pg[e], ps[e]) + (float)rv[e]);
+        }
         *reinterpret_cast<bf16x8*>(out + base + r * c + piece * 8) = o;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Depthwise temporal convolution (Conv3d(C, C, (k,1,1), padding (k/2,0,0), groups=C) of
+// video_diffusion_guidance.py:324-325) over channels-last rows [b][f][hw][c]: a k-tap filter along the frame
+// axis per channel.  One thread per 8 channels of an output row; neighbouring frames are hw rows away.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void temporal_dwconv_kernel(const __bf16* __restrict__ x, int ldx, __bf16* __restrict__ out,
+                                                              int ldo, long long rows, int f, long long hw, int c, int k,
+                                                              const float* __restrict__ w, const float* __restrict__ bias) {
+    const int ppr = c / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = idx / ppr;
+    const int piece = (int)(idx - r * ppr);
+    if (r >= rows) return;
+    const int fr = (int)((r / hw) % f);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[piece * 8 + e] : 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int ff = fr + j - k / 2;
+        if (ff < 0 || ff >= f) continue;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (r + (long long)(j - k / 2) * hw) * ldx + piece * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf((float)v[e], w[(piece * 8 + e) * k + j], acc[e]);
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+    *reinterpret_cast<bf16x8*>(out + r * ldo + piece * 8) = o;
 }
 
 static int groupnorm_splits(int64_t rows_per_sample) {
@@ -705,10 +752,13 @@ extern "C" size_t vdmi_groupnorm_workspace_bytes(int nsamples, int64_t rows_per_
     return (size_t)nsamples * groupnorm_splits(rows_per_sample) * (c / 8) * 2 * sizeof(float);
 }
 
-extern "C" int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
-                                   const float* gamma, const float* beta, float eps, void* workspace,
-                                   vdmi_stream stream_) {
+extern "C" int vdmi_groupnorm(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
+                              const float* gamma, const float* beta, float eps, int act, const float* post_gain,
+                              const float* post_shift, int64_t post_bstride, const void* residual, int ld_res,
+                              void* workspace, vdmi_stream stream_) {
     if (!x || !out || !gamma || !beta || !workspace) return VDMI_E_ARG;
+    if (act < 0 || act > 1 || (post_shift && !post_gain) || (residual && (ld_res < c || ld_res % 8 || !aligned16(residual))))
+        return VDMI_E_ARG;
     if (nsamples <= 0 || nsamples > 65535 || rows_per_sample <= 0 || c < 64 || c > 2048 || 256 % (c / 8) || c % 8 ||
         groups <= 0 || groups > 256 || c % groups || (c / groups) % 8)
         return VDMI_E_SHAPE;
@@ -721,7 +771,29 @@ extern "C" int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64
     VDMI_LAUNCH_CHECK();
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)nsplit, (unsigned)nsamples), dim3(256), 0, stream,
                        static_cast<const __bf16*>(x), static_cast<__bf16*>(out), (long long)rows_per_sample, c, groups,
-                       part, nsplit, gamma, beta, eps);
+                       part, nsplit, gamma, beta, eps, act, post_gain, post_shift, (long long)post_bstride,
+                       static_cast<const __bf16*>(residual), ld_res);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
+                                   const float* gamma, const float* beta, float eps, void* workspace,
+                                   vdmi_stream stream) {
+    return vdmi_groupnorm(x, out, nsamples, rows_per_sample, c, groups, gamma, beta, eps, 1, nullptr, nullptr, 0, nullptr, 0,
+                          workspace, stream);
+}
+
+extern "C" int vdmi_temporal_dwconv(const void* x, int ldx, void* out, int ldo, int b, int f, int64_t hw, int c, int k,
+                                    const float* w, const float* bias, vdmi_stream stream) {
+    if (!x || !out || !w) return VDMI_E_ARG;
+    if (b <= 0 || f <= 0 || hw <= 0 || c <= 0 || c % 8 || k < 1 || !(k & 1) || ldx < c || ldo < c || ldx % 8 || ldo % 8)
+        return VDMI_E_SHAPE;
+    if (!aligned16(x) || !aligned16(out)) return VDMI_E_ALIGN;
+    const long long rows = (long long)b * f * hw, threads = rows * (c / 8), blocks = (threads + 255) / 256;
+    if (blocks > 0x7fffffffLL) return VDMI_E_SHAPE;
+    hipLaunchKernelGGL(temporal_dwconv_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const __bf16*>(x), ldx, static_cast<__bf16*>(out), ldo, rows, f, (long long)hw, c, k, w, bias);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }

@@ -248,13 +248,15 @@ class Plan:
         self._tapgemm(a, name + ".temporal_conv")
         return y
 
-    def _sta(self, name, st, x, c, h, w) -> torch.Tensor:
+    def _sta(self, name, st, x, c, h, w, per_frame: bool = False) -> torch.Tensor:
         """Residual(PreNorm(SpatioTemporalAttention)) (reference version1diffusion.py:325-345): full softmax
         attention over the F*h*w tokens of a sample; the keys/values are the layer's own projection, repacked
-        into the operand order of the cross-attention core."""
+        into the operand order of the cross-attention core.  per_frame: the h*w tokens of each frame instead
+        (SpatialAttention of video_diffusion_guidance.py:431-459)."""
         lib = _lib.lib()
         frames, hw = self.B * self.F, h * w
-        rows, hid, n_tok = frames * hw, st["hid"], self.F * hw
+        rows, hid = frames * hw, st["hid"]
+        n_tok, ngrp = (hw, frames) if per_frame else (self.F * hw, self.B)
         heads = hid // 32
         qkv = self._buf(rows, 3 * hid)
         a = self._base_args(frames, h, w, qkv, 3 * hid, EPI_QKV_ATTN)
@@ -262,13 +264,13 @@ class Plan:
         a.colsum = _ptr(st["wqkv"].colsum)
         a.ln_eps, a.q_scale = 1e-5, st["scale"] * math.log2(math.e)
         self._tapgemm(a, name + ".qkv")
-        kvp = torch.empty(lib.vdmi_xattn_kv_elems(1, self.B, n_tok, heads), device=self.device, dtype=torch.bfloat16)
+        kvp = torch.empty(lib.vdmi_xattn_kv_elems(1, ngrp, n_tok, heads), device=self.device, dtype=torch.bfloat16)
         self.keep.append(kvp)
-        self._add(lambda s, qkv=qkv: lib.vdmi_xattn_pack_kv(qkv.data_ptr() + 2 * hid, 3 * hid, kvp.data_ptr(), 1, self.B,
+        self._add(lambda s, qkv=qkv: lib.vdmi_xattn_pack_kv(qkv.data_ptr() + 2 * hid, 3 * hid, kvp.data_ptr(), 1, ngrp,
                                                             n_tok, heads, s), None, name + ".pack_kv")
         o = self._buf(rows, hid)
         meta = {"kernel": "xattn_core", "flops": 4.0 * rows * hid * ((n_tok + 31) // 32) * 32, "bytes": 4.0 * rows * hid}
-        self._add(lambda s, qkv=qkv, o=o: lib.vdmi_xattn_core(qkv.data_ptr(), 3 * hid, o.data_ptr(), kvp.data_ptr(), self.B,
+        self._add(lambda s, qkv=qkv, o=o: lib.vdmi_xattn_core(qkv.data_ptr(), 3 * hid, o.data_ptr(), kvp.data_ptr(), ngrp,
                                                               n_tok, n_tok, heads, s), meta, name + ".core")
         y = self._buf(rows, c)
         b = self._base_args(frames, h, w, y, c, EPI_PLAIN)
@@ -562,6 +564,8 @@ class Plan:
 
 
 class UnetEngine:
+    plan_class = Plan
+
     def __init__(self, unet):
         self.unet = unet
         self.packed = None
@@ -570,8 +574,12 @@ class UnetEngine:
         self._const_cache: Dict[Tuple, object] = {}
 
     # -- parameter packing -----------------------------------------------------------------
+    def _rotary(self):
+        pre = self.unet.init_temporal_attn.fn
+        return (pre.fn.fn if hasattr(pre.fn, "fn") else pre.fn).rotary_emb
+
     def _param_key(self, device):
-        rot = self.unet.init_temporal_attn.fn.fn.fn.rotary_emb
+        rot = self._rotary()
         return (str(device), getattr(rot, "convention", "half")) + \
             tuple((p.data_ptr(), p._version) for p in self.unet.parameters())
 
@@ -626,7 +634,7 @@ class UnetEngine:
     def _pack_attn(self, res_mod, device, dim_head):
         """Residual(PreNorm(EinopsToAndFrom(Attention)))"""
         pre = res_mod.fn
-        att = pre.fn.fn
+        att = pre.fn.fn if hasattr(pre.fn, "fn") else pre.fn       # with or without the EinopsToAndFrom wrapper
         gamma = pre.norm.gamma.detach().float().reshape(-1).cpu()
         wq = att.to_qkv.weight.detach().float().cpu() * gamma[None, :]        # LayerNorm gamma folded in
         hid = att.to_out.weight.shape[1]
@@ -634,7 +642,7 @@ class UnetEngine:
         if att.rotary_emb is not None and getattr(att.rotary_emb, "convention", "half") == "interleaved":
             # rot_interleaved(x) = P^-1 rot_half(P x) with P the even/odd de-interleave of a head's features:
             # apply P to the q and k rows (v and the scores are unaffected)
-            dh = att.dim_head
+            dh = getattr(att, "dim_head", 32)
             perm = torch.cat([torch.arange(0, dh, 2), torch.arange(1, dh, 2)])
             idx = torch.arange(3 * hid)
             for blk in (0, 1):
@@ -822,7 +830,7 @@ class UnetEngine:
         """cos/sin of position * inv_freq, [F][16] float32 (half-split rotary, 32-dim heads)."""
         key = ("rot", nf)
         if key not in self._const_cache:
-            inv = self.unet.init_temporal_attn.fn.fn.fn.rotary_emb.inv_freq.detach().float().cpu()
+            inv = self._rotary().inv_freq.detach().float().cpu()
             ang = torch.arange(nf).float()[:, None] * inv[None, :]
             self._const_cache[key] = (ang.cos().to(device).contiguous(), ang.sin().to(device).contiguous())
         return self._const_cache[key]
@@ -833,7 +841,7 @@ class UnetEngine:
         self.ensure_packed(device)
         key = (B, F, H, W, str(device), L)
         if key not in self._plans:
-            self._plans[key] = Plan(self, B, F, H, W, device, L=L)
+            self._plans[key] = self.plan_class(self, B, F, H, W, device, L=L)
         return self._plans[key]
 
     @torch.no_grad()
