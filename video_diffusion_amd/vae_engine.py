@@ -184,7 +184,7 @@ class VaeDecodePlan(_ConvPlan):
         lib = _lib.lib()
         seq = dec.decoder
         latent, c0 = seq[0].in_channels, seq[0].out_channels
-        self.z_in = torch.zeros(B, latent, F, h, w, device=device, dtype=torch.float32)
+        self.z_in = self.x_in = torch.zeros(B, latent, F, h, w, device=device, dtype=torch.float32)
         frames = self.frames
         # 0: 1x1 conv from the latent (fp32 channels-first) -> bf16 rows
         w0 = self.f32(seq[0].weight.reshape(c0, latent))
@@ -222,31 +222,6 @@ class VaeDecodePlan(_ConvPlan):
         self.keep.append(sel)
         self.calls.append((lambda s, x=x, c=c: lib.vdmi_final_conv(
             x.data_ptr(), sel.data_ptr(), None, self.out.data_ptr(), B, c, F, ch, cw, cout, s), "to_channels_first"))
-
-
-class VaeDecodeEngine:
-    """Plans per latent shape; weights are re-packed when the decoder's parameters change."""
-
-    def __init__(self, decoder):
-        self.decoder = decoder
-        self._plans: Dict[Tuple, VaeDecodePlan] = {}
-        self._key = None
-
-    def decode(self, z: torch.Tensor) -> torch.Tensor:
-        if z.device.type != "cuda":
-            raise _lib.VdmiError("the HIP VAE decoder needs a GPU tensor")
-        key = (str(z.device),) + tuple((p.data_ptr(), p._version) for p in self.decoder.parameters())
-        if key != self._key:
-            self._plans.clear()
-            self._key = key
-        B, _, F, h, w = z.shape
-        pkey = (B, F, h, w)
-        plan = self._plans.get(pkey)
-        if plan is None:
-            plan = self._plans[pkey] = VaeDecodePlan(self.decoder, B, F, h, w, z.device)
-        plan.z_in.copy_(z.to(torch.float32))
-        plan.run()
-        return plan.out.clone()
 
 
 class _ShapeCachedEngine:
@@ -287,3 +262,10 @@ class FrameEncodeEngine(_ShapeCachedEngine):
     def encode(self, prev_latents):
         plan = self._plan(prev_latents)
         return plan.out.float().reshape(plan.B, plan.tokens, plan.dim)
+
+
+class VaeDecodeEngine(_ShapeCachedEngine):
+    plan_cls = VaeDecodePlan
+
+    def decode(self, z):
+        return self._plan(z).out.clone()
