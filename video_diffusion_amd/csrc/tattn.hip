@@ -54,7 +54,13 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
     return f;
 }
 
-template <int C, bool RES, int NWAVES>
+// FOLD: the relative-position bias and the block-diagonal site mask are a 16-feature extension of the score
+// product (one more MFMA into the same accumulator) instead of 32 vector instructions per head:
+//   key side   [bias[h][0..F-1][frame(key)] * log2 e,  2^50 * onehot(site(key)) over g+1 sites (the last = padding rows)]
+//   query side [onehot(frame(query)),                  -2^50 * (1 - onehot(site(query)))]
+// so a key of another site (or a padding row) gets -2^100 and a key of the query's own site gets exactly its bias
+// (in bf16).  Needs F + floor(32/F) + 1 <= 16 and no focus-present flags.
+template <int C, bool RES, int NWAVES, bool FOLD>
 __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArgs a) {
     constexpr int KS = C / 16, CT = C / 32, NFRAG = 3 * KS + 2 * CT, SLICE = NFRAG * 512;
     constexpr int NTHR = NWAVES * 64;
@@ -67,10 +73,23 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int F = a.F, g = a.sites_per_group;
 
-    // bias table expanded to the 32 key rows of a group: [head][query frame][key row], times log2 e
-    for (int i = tid; i < a.heads * F * 32; i += NTHR) {
-        const int row = i & 31, hq = i >> 5;
-        biasl[i] = a.bias ? a.bias[hq * F + row % F] * LOG2E : 0.f;
+    __bf16* kxl = reinterpret_cast<__bf16*>(biasl);      // FOLD: [head][32 key rows][16 features]
+    if constexpr (FOLD) {
+        for (int i = tid; i < a.heads * 512; i += NTHR) {
+            const int slot = i & 15, row = (i >> 4) & 31, head = i >> 9;
+            const bool valid = row < g * F;
+            const int kf = row % F, site = valid ? row / F : g;
+            float v = 0.f;
+            if (slot < F) v = (valid && a.bias) ? a.bias[(head * F + slot) * F + kf] * LOG2E : 0.f;
+            else if (slot < F + g + 1) v = (slot - F == site) ? 1125899906842624.f : 0.f;      // 2^50
+            kxl[i] = f2bf(v);
+        }
+    } else {
+        // bias table expanded to the 32 key rows of a group: [head][query frame][key row], times log2 e
+        for (int i = tid; i < a.heads * F * 32; i += NTHR) {
+            const int row = i & 31, hq = i >> 5;
+            biasl[i] = a.bias ? a.bias[hq * F + row % F] * LOG2E : 0.f;
+        }
     }
     if constexpr (RES) {
         const int pieces = a.heads * SLICE / 8;
@@ -88,6 +107,19 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
         const int ks = acc_row(r, half) / F;
         if (ks == q_site && ks < g) kmask_all |= 1u << r;
         if (acc_row(r, half) == l31 && ks < g) kmask_self |= 1u << r;
+    }
+    // FOLD: this lane's query-side features (k-slots 8*half .. 8*half+7 of the extra step)
+    bf16x8 qx = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (FOLD) {
+        const int qs_idx = l31 < g * F ? q_site : g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int slot = 8 * half + j;
+            float v = 0.f;
+            if (slot < F) v = (slot == q_f) ? 1.f : 0.f;
+            else if (slot < F + g + 1) v = (slot - F == qs_idx) ? 0.f : -1125899906842624.f;
+            qx[j] = f2bf(v);
+        }
     }
     f32x4 rc[2], rs[2];
 #pragma unroll
@@ -196,20 +228,30 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
                     k[r + 8] = k2 * rc[rg][e] + k1 * rs[rg][e];
                 }
             // ---- S^T = K Q^T, softmax over keys (this lane's 16 registers + the other half) --------
-            f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 0), acc_frag(q, 0), zero, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 1), acc_frag(q, 1), st, 0, 0, 0);
-            const float* bl = biasl + (head * F + q_f) * 32 + 4 * half;
+            f32x16 st;
             float mx = -1e30f;
+            if constexpr (FOLD) {
+                const bf16x8 kx = *reinterpret_cast<const bf16x8*>(kxl + (head * 32 + l31) * 16 + 8 * half);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx, qx, zero, 0, 0, 0);          // bias + mask
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 0), acc_frag(q, 0), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 1), acc_frag(q, 1), st, 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 8 * u);     // key rows of registers 4u..4u+3
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+            } else {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 0), acc_frag(q, 0), zero, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 1), acc_frag(q, 1), st, 0, 0, 0);
+                const float* bl = biasl + (head * F + q_f) * 32 + 4 * half;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * u + e;
-                    // keys of other sites (and padding rows) get -1e30: exp2 below turns them into exact zeros
-                    const float sv = st[r] + ((kmask >> r) & 1u ? b4[e] : -1e30f);
-                    st[r] = sv;
-                    mx = fmaxf(mx, sv);
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 8 * u);     // key rows of registers 4u..4u+3
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * u + e;
+                        // keys of other sites (and padding rows) get -1e30: exp2 below turns them into exact zeros
+                        const float sv = st[r] + ((kmask >> r) & 1u ? b4[e] : -1e30f);
+                        st[r] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -319,7 +361,8 @@ extern "C" int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const
     a.q_scale = q_scale;
     a.eps = eps;
     const int nfrag = 3 * (c / 16) + 2 * (c / 32);
-    const size_t bias_bytes = (size_t)heads * f * 32 * 4;
+    const bool fold = !focus && f + 32 / f + 1 <= 16;
+    const size_t bias_bytes = fold ? (size_t)heads * 1024 : (size_t)heads * f * 32 * 4;
     // all heads resident (and 12 waves per workgroup, 3 per SIMD) when they fit beside the bias table
     const size_t lds_res = (size_t)heads * nfrag * 1024 + bias_bytes, lds_dbuf = (size_t)2 * nfrag * 1024 + bias_bytes;
     const bool res = c <= 64 && lds_res <= 150 * 1024;
@@ -329,24 +372,26 @@ extern "C" int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const
     const int rounds = (a.ngroups + nwaves - 1) / nwaves;
     const int grid = rounds < 256 ? rounds : 256;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define VDMI_TATTN_CASE(C_, RES_, NW_)                                                                        \
-    if (c == C_ && res == RES_) {                                                                             \
+#define VDMI_TATTN_CASE_(C_, RES_, NW_, FOLD_)                                                                \
+    if (c == C_ && res == RES_ && fold == FOLD_) {                                                            \
         static bool attr_done = false;                                                                        \
         if (!attr_done) {                                                                                     \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<C_, RES_, NW_>),         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<C_, RES_, NW_, FOLD_>),  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)    \
                 return VDMI_E_LAUNCH;                                                                         \
             attr_done = true;                                                                                 \
         }                                                                                                     \
-        hipLaunchKernelGGL((tattn_fused_kernel<C_, RES_, NW_>), dim3(grid), dim3(NW_ * 64), lds, st, a);      \
+        hipLaunchKernelGGL((tattn_fused_kernel<C_, RES_, NW_, FOLD_>), dim3(grid), dim3(NW_ * 64), lds, st, a); \
         VDMI_LAUNCH_CHECK();                                                                                  \
         return VDMI_OK;                                                                                       \
     }
+#define VDMI_TATTN_CASE(C_, RES_, NW_) VDMI_TATTN_CASE_(C_, RES_, NW_, true) VDMI_TATTN_CASE_(C_, RES_, NW_, false)
     VDMI_TATTN_CASE(32, true, 12)
     VDMI_TATTN_CASE(64, true, 12)
     VDMI_TATTN_CASE(32, false, 8)
     VDMI_TATTN_CASE(64, false, 8)
     VDMI_TATTN_CASE(128, false, 8)
 #undef VDMI_TATTN_CASE
+#undef VDMI_TATTN_CASE_
     return VDMI_E_SHAPE;
 }

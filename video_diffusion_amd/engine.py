@@ -89,8 +89,10 @@ class _Call:
 class Plan:
     """All launches of one Unet3D forward for a fixed (B, F, H, W)."""
 
-    def __init__(self, eng: "UnetEngine", B: int, F: int, H: int, W: int, device, build: bool = True, L: int = 0):
+    def __init__(self, eng: "UnetEngine", B: int, F: int, H: int, W: int, device, build: bool = True, L: int = 0,
+                 focus: bool = False):
         self.eng, self.B, self.F, self.H, self.W, self.device = eng, B, F, H, W, device
+        self.focus_enabled = focus            # temporal attentions read the focus-present flags (focus_in)
         self.L = L                            # context tokens per sample of the frame cross-attention (0: layers skipped)
         self.calls: List[_Call] = []
         self.ctx_calls: List[_Call] = []      # key/value projection of the context: once per context, not per step
@@ -282,7 +284,7 @@ class Plan:
     def _attention(self, name, at, x, c, h, w, temporal: bool, focus: bool = False) -> torch.Tensor:
         """Residual(PreNorm(Attention)) over frames (temporal) or over the h*w positions (spatial).
         focus: the layer receives the focus-present mask (self.focus_in, reference vdp.py:800, 812, 821)."""
-        fptr = self.focus_in.data_ptr() if focus else None
+        fptr = self.focus_in.data_ptr() if (focus and self.focus_enabled) else None
         lib = _lib.lib()
         frames, hw = self.B * self.F, h * w
         rows = frames * hw
@@ -836,12 +838,14 @@ class UnetEngine:
         return self._const_cache[key]
 
     # -- execution -------------------------------------------------------------------------------
-    def plan(self, B, F, H, W, device, L: int = 0) -> Plan:
-        """L > 0: with the frame cross-attention layers, for contexts of L tokens per sample."""
+    def plan(self, B, F, H, W, device, L: int = 0, focus: bool = False) -> Plan:
+        """L > 0: with the frame cross-attention layers, for contexts of L tokens per sample.  focus: the temporal
+        attentions honour the focus-present flags (a separate plan: without them the fused kernel folds bias and
+        mask into its score product)."""
         self.ensure_packed(device)
-        key = (B, F, H, W, str(device), L)
+        key = (B, F, H, W, str(device), L, focus)
         if key not in self._plans:
-            self._plans[key] = self.plan_class(self, B, F, H, W, device, L=L)
+            self._plans[key] = self.plan_class(self, B, F, H, W, device, L=L, focus=focus)
         return self._plans[key]
 
     @torch.no_grad()
@@ -859,7 +863,8 @@ class UnetEngine:
             if frame_cond_features.dim() != 3 or frame_cond_features.shape[0] != B:
                 raise ValueError("frame_cond_features must be (batch, tokens, frame_cond_dim)")
             L = frame_cond_features.shape[1]
-        plan = self.plan(B, F, H, W, x.device, L)
+        use_focus = focus_present_mask is not None or prob_focus_present != 0
+        plan = self.plan(B, F, H, W, x.device, L, focus=use_focus)
         plan.x_in.copy_(x.to(torch.float32))
         plan.t_in.copy_(time.to(torch.int64))
         if L:
