@@ -248,7 +248,7 @@ def test_mid_spatial_attention(tiny):
     L, sd, cfg, B, Fr, H = tiny["L"], tiny["sd"], tiny["cfg"], tiny["B"], tiny["F"], tiny["H"]
     h = H // 2
     x = bf16_round(inp("tiny.a64h", (B, 64, Fr, h, h), scale=1.5))
-    y = L.run(lambda plan, P: plan._attention("mid_spatial_attn", P["mid_spatial_attn"], to_rows(x), 64, h, h, False))
+    y = L.run(lambda plan, P: plan._sta("mid_spatial_attn", P["mid_spatial_attn"], to_rows(x), 64, h, h, per_frame=True))
     ref = O.spatial_attn_residual(sd, "mid_spatial_attn", x, cfg)
     assert rel_err(from_rows(y, B, Fr, h, h), ref) < LAYER_TOL
 

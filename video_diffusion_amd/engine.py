@@ -516,7 +516,7 @@ class Plan:
                 h, w = (h + 2 - 4) // 2 + 1, (w + 2 - 4) // 2 + 1
 
         x = self._resnet("mid_block1", P["mid_block1"], [(x, c)], h, w)
-        x = self._attention("mid_spatial_attn", P["mid_spatial_attn"], x, c, h, w, False)
+        x = self._sta("mid_spatial_attn", P["mid_spatial_attn"], x, c, h, w, per_frame=True)
         x = self._attention("mid_temporal_attn", P["mid_temporal_attn"], x, c, h, w, True, focus=True)
         x = self._resnet("mid_block2", P["mid_block2"], [(x, c)], h, w)
         self.taps["mid"] = x
@@ -696,7 +696,8 @@ class UnetEngine:
     def _pack_sta(self, res_mod, device):
         """Residual(PreNorm(SpatioTemporalAttention)): q|k|v projection with the LayerNorm gamma folded in; the
         out-projection's input columns follow the feature order vdmi_xattn_core writes."""
-        pre, st = res_mod.fn, res_mod.fn.fn
+        pre = res_mod.fn
+        st = pre.fn.fn if hasattr(pre.fn, "fn") else pre.fn       # with or without the EinopsToAndFrom wrapper
         gamma = pre.norm.gamma.detach().float().reshape(-1).cpu()
         wq = st.to_qkv.weight.detach().float().cpu() * gamma[None, :]
         hid = st.to_out.weight.shape[1]
@@ -786,7 +787,7 @@ class UnetEngine:
             P["downs"].append(L)
         mid = dims[-1]
         P["mid_block1"] = self._pack_resnet(u.mid_block1, device, (mid, 0), stacked)
-        P["mid_spatial_attn"] = self._pack_attn(u.mid_spatial_attn, device, 32)
+        P["mid_spatial_attn"] = self._pack_sta(u.mid_spatial_attn, device)     # MFMA attention core, one group per frame
         P["mid_temporal_attn"] = self._pack_attn(u.mid_temporal_attn, device, u.attn_dim_head)
         P["mid_block2"] = self._pack_resnet(u.mid_block2, device, (mid, 0), stacked)
         P["ups"] = []
