@@ -105,7 +105,10 @@ class Plan:
         self.focus_in = torch.zeros(B, device=device, dtype=torch.uint8)     # focus-present mask, all False by default
         self.eps_out = torch.empty(B, u.out_dim, F, H, W, device=device, dtype=torch.float32)
         self.taps: Dict[str, torch.Tensor] = {}   # named intermediate activations (for tests)
+        self.join_index = None      # index of the first call that reads the time-embedding tables
+        self._side = None
         self._setup()
+        self.n_embed_calls = len(self.calls)
         if build:
             self._build()
 
@@ -143,6 +146,8 @@ class Plan:
     # -- layer builders ---------------------------------------------------------------------
     def _block(self, name, pk, srcs, h, w, gain, shift, bstride, res=None) -> torch.Tensor:
         """Block: conv3x3 + RMSNorm + scale/shift + SiLU, optionally + residual (res_conv or identity)."""
+        if self.join_index is None:
+            self.join_index = len(self.calls)
         frames = self.B * self.F
         (s0, c0), (s1, c1) = srcs[0], (srcs[1] if len(srcs) > 1 else (None, 0))
         w_pack, bias = pk
@@ -557,9 +562,26 @@ class Plan:
                 check(st, call.name)
 
     def run(self):
-        """Enqueue every launch on the current stream (no synchronisation)."""
-        s = _stream()
-        for call in self.calls:
+        """Enqueue every launch (no host synchronisation).  The time-embedding kernels (the first calls) do not
+        depend on the image: they go to a side stream and are joined right before the first block that needs the
+        scale/shift tables, so they overlap the init conv and the first temporal attention - also inside a captured
+        HIP graph, where the fork / join becomes graph edges."""
+        main = torch.cuda.current_stream(self.device)
+        s = main.cuda_stream
+        first, join = 0, self.join_index
+        if join is not None and join > self.n_embed_calls:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(main)
+            for call in self.calls[:self.n_embed_calls]:
+                st = call.fn(self._side.cuda_stream)
+                if st != 0:
+                    check(st, call.name)
+            first = self.n_embed_calls
+        for i in range(first, len(self.calls)):
+            if first and i == join:
+                main.wait_stream(self._side)
+            call = self.calls[i]
             st = call.fn(s)
             if st != 0:
                 check(st, call.name)

@@ -182,6 +182,8 @@ class GuidancePlan(Plan):
 
     def _gres(self, name, rb, srcs, h, w, use_time=True):
         """ResnetBlock of the variant (video_diffusion_guidance.py:345-388)."""
+        if self.join_index is None:
+            self.join_index = len(self.calls)
         rows = self.B * self.F * h * w
         n = rb["ts1"]["w"].n
         if rb["res"] is not None:
