@@ -76,10 +76,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("for --gpus N > 1 launch through `python -m torch.distributed.run --nproc-per-node N`")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; VDMI_BENCH_BACKEND=gloo lets several ranks rehearse the multi-rank path on one card
+    backend = os.environ.get("VDMI_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from video_diffusion_amd import GaussianDiffusion, Unet3D
     from video_diffusion_amd.parallel import gather_videos
