@@ -51,7 +51,8 @@ struct PassDev {
     int ntaps;
     int min_dy, min_dx;
     int ph, pw;
-    int toff[VDMI_MAX_TAPS];
+    int toff[VDMI_MAX_TAPS];   // LDS offset of each tap inside the patch, in elements (line skew included)
+    int lskew;                 // extra elements between consecutive patch lines (a multiple of 8; see pick_lskew)
     const __bf16* w;
     long long w_group_stride;
     int w_group_frames;
@@ -126,7 +127,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
             const int fi = min(py / g.fs_rows, g.fstack - 1);
             prow = fi * g.phf + (py - fi * g.fs_rows) * g.stride;
         }
-        rowoff[j] = (prow * g.pw + px * g.stride) * PROW + (lane >> 5) * 8;
+        rowoff[j] = (prow * g.pw + px * g.stride) * PROW + prow * g.lskew + (lane >> 5) * 8;
     }
     const int iy0 = ty * TH * g.stride + g.min_dy, ix0 = tx * TW * g.stride + g.min_dx;
     const __bf16* wg = g.w + (long long)nt * BN * BKC;
@@ -217,6 +218,15 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     };
     auto patch_commit = [&]() {
         if constexpr (!STATS) {
+            if (g.lskew) {
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const int r = r0 + u * RSTEP;
+                    const int ry = (int)(((float)r + 0.5f) * g.inv_pw);
+                    if (r < nrows) *reinterpret_cast<bf16x8*>(patch + r * PROW + ry * g.lskew + piece * 8) = pv[u];
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < LB; ++u)
                 if (r0 + u * RSTEP < nrows) *reinterpret_cast<bf16x8*>(patch + (r0 + u * RSTEP) * PROW + piece * 8) = pv[u];
@@ -270,7 +280,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
 #if !defined(VDMI_ABL) || VDMI_ABL != 3
             if (s + 1 < nsteps) load_w(s + 1);
 #endif
-            const int to = g.toff[tap0 + t] * PROW;
+            const int to = g.toff[tap0 + t];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 af[MI], bfr[NJ];
@@ -679,17 +689,57 @@ int build_pass(const vdmi_tap_pass& p, int bkc, int npad, PassDev* d) {
     return VDMI_OK;
 }
 
-void finish_pass(const vdmi_tap_pass& p, PassDev* d, int th, int tw) {
+void finish_pass(const vdmi_tap_pass& p, PassDev* d, int th, int tw, int bkc, int lskew) {
     const int span_y = d->ph, span_x = d->pw;
     d->ph = (th - 1) * p.stride + span_y + 1;
     d->pw = (tw - 1) * p.stride + span_x + 1;
-    for (int t = 0; t < p.ntaps; ++t) d->toff[t] = (p.dy[t] - d->min_dy) * d->pw + (p.dx[t] - d->min_dx);
+    d->lskew = lskew;
+    for (int t = 0; t < p.ntaps; ++t) {
+        const int ly = p.dy[t] - d->min_dy;
+        d->toff[t] = (ly * d->pw + (p.dx[t] - d->min_dx)) * (bkc + 8) + ly * lskew;
+    }
 }
 
-size_t lds_bytes(const TileCfg& c, int patch_rows) {
+// A wave reads its pixel fragments from the patch with ds_read_b128: lane l (pixel l & 31 of the wave's 32) takes 16
+// bytes at row(l) * (bkc + 8) * 2 + 16 * (l >> 5).  The LDS serves such a read in four groups of 16 lanes, and the 16
+// addresses of a group are conflict-free only when their 16-byte slots differ mod 16.  Consecutive patch rows do
+// (the row pitch is an odd number of slots), but a tile narrower than 32 pixels puts several patch lines into one
+// group, and with the halo the line pitch is not a multiple of 16 slots: every fragment read then takes 2-3x its
+// cycles.  Skewing each patch line by a few 16-byte slots restores distinct slots; the best skew is found by
+// enumerating the groups, among those whose extra bytes (`lines` patch lines) keep the workgroup within the LDS it
+// would otherwise use per CU slot (two workgroups per CU when the unskewed layout allows that).  Returns the skew in
+// elements per line.
+int pick_lskew(int ltw, int pw, int stride, int bkc, int lines, size_t lds_unskewed) {
+    if (bkc != 64 || (1 << ltw) >= 32) return 0;
+    const size_t cap = lds_unskewed <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
+    if (lds_unskewed > cap) return 0;
+    const size_t budget = cap - lds_unskewed;
+    static const int group_of[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0,
+                                     1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+    const int slots_per_row = (bkc + 8) / 8, tw = 1 << ltw;
+    int best = 0, best_extra = 1 << 30;
+    for (int skew = 0; skew < 16; ++skew) {
+        if ((size_t)lines * skew * 16 > budget) break;
+        int extra = 0;
+        for (int g = 0; g < 2; ++g) {
+            int cnt[16] = {0}, mx = 0;
+            for (int l = 0; l < 32; ++l) {
+                if (group_of[l] != g) continue;
+                const int line = (l >> ltw) * stride, px = (l & (tw - 1)) * stride;
+                const int slot = ((line * pw + px) * slots_per_row + line * skew) & 15;
+                mx = ++cnt[slot] > mx ? cnt[slot] : mx;
+            }
+            extra += mx - 1;
+        }
+        if (extra < best_extra) { best_extra = extra; best = skew; }
+    }
+    return best * 8;
+}
+
+size_t lds_bytes(const TileCfg& c, int patch_rows, int skew_elems = 0) {
     const int nwn = c.bn / c.wn, nwaves = (c.bm / c.wm) * nwn;
     const size_t main_loop = (size_t)2 * c.bn * c.bkc * 2 + (size_t)3 * c.bn * 4 + (size_t)nwn * c.bm * 4 +
-                             (size_t)2 * c.bm * 4 + (size_t)patch_rows * (c.bkc + 8) * 2;
+                             (size_t)2 * c.bm * 4 + (size_t)patch_rows * (c.bkc + 8) * 2 + (size_t)skew_elems * 2;
     const size_t staging = (size_t)nwaves * c.wm * (c.wn + 8) * 2;   // output transpose, reuses the same LDS
     return main_loop > staging ? main_loop : staging;
 }
@@ -818,14 +868,15 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         // choose the tile shape (TH x TW = bm, TW a power of two) with the fewest tiles that fits LDS
         int best_ltw = -1;
         long long best_tiles = 0;
-        int best_rows = 0;
+        int best_rows = 0, best_skew = 0, best_ph = 0;
         for (int ltw = 0; (1 << ltw) <= c.bm; ++ltw) {
             const int tw = 1 << ltw, th = c.bm >> ltw;
             if (flat && th != 1) continue;
             const int ph = (th - 1) * mainp.stride + k.main.ph + 1, pw = (tw - 1) * mainp.stride + k.main.pw + 1;
             int rows = ph * pw;
             if (A.has_res == 1 && c.bm > rows) rows = c.bm;
-            if (lds_bytes(c, rows) > kLdsMax) continue;
+            const int skew = (flat || is_qkv) ? 0 : pick_lskew(ltw, pw, mainp.stride, c.bkc, ph, lds_bytes(c, rows));
+            if (lds_bytes(c, rows, ph * skew) > kLdsMax) continue;
             {   // the loader keeps a whole chunk of the patch in registers: rows it can cover
                 if (!is_qkv && rows > patch_row_cap(c)) continue;
             }
@@ -834,6 +885,8 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
                 best_ltw = ltw;
                 best_tiles = tiles;
                 best_rows = rows;
+                best_skew = skew;
+                best_ph = ph;
             }
         }
         // images smaller than the pixel tile: stack whole frames into one tile (shared weights only)
@@ -846,20 +899,23 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
                 const int fs = th / grid_h < frames ? th / grid_h : frames;
                 const int phf = (grid_h - 1) * mainp.stride + k.main.ph + 1, pw = (tw - 1) * mainp.stride + k.main.pw + 1;
                 const int rows = fs * phf * pw;
-                if (lds_bytes(c, rows) > kLdsMax || rows > patch_row_cap(c)) continue;
+                const int skew = pick_lskew(ltw, pw, mainp.stride, c.bkc, fs * phf, lds_bytes(c, rows));
+                if (lds_bytes(c, rows, fs * phf * skew) > kLdsMax || rows > patch_row_cap(c)) continue;
                 const long long blocks = (frames + fs - 1) / fs;
                 if (blocks < best_blocks) {
                     best_blocks = blocks;
                     best_ltw = ltw;
                     best_tiles = 1;
                     best_rows = rows;
+                    best_skew = skew;
+                    best_ph = fs * phf;
                     fstack = fs;
                 }
             }
         }
         if (best_ltw < 0) continue;   // try a smaller pixel tile
         const int tw = 1 << best_ltw, th = c.bm >> best_ltw;
-        finish_pass(mainp, &k.main, th, tw);
+        finish_pass(mainp, &k.main, th, tw, c.bkc, best_skew);
         k.main.fstack = fstack;
         k.main.nframes = frames;
         if (fstack > 1) {
@@ -872,7 +928,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         k.main.inv_phf = k.main.phf > 0 ? 1.0f / (float)k.main.phf : 0.f;
         if (A.has_res == 1) {
             k.res = res_base;
-            finish_pass(A.res, &k.res, th, tw);
+            finish_pass(A.res, &k.res, th, tw, c.bkc, 0);
             k.res.inv_pw = 1.0f / (float)k.res.pw;
             k.res.inv_phf = 0.f;
         }
@@ -919,7 +975,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         if (best_tiles > 0x7fffffffLL || frames > 65535) return VDMI_E_SHAPE;
         const dim3 grid((unsigned)best_tiles, (unsigned)(npad / c.bn), (unsigned)frames);
         if (grid.y > 65535) return VDMI_E_SHAPE;
-        const size_t lds = lds_bytes(c, best_rows);
+        const size_t lds = lds_bytes(c, best_rows, best_ph * best_skew);
 
 #define VDMI_CASE(BM_, BN_, WM_, WN_, BKC_, EPI_)                                                   \
     if (c.bm == BM_ && c.bn == BN_ && c.wm == WM_ && c.wn == WN_ && c.bkc == BKC_ && epi == EPI_)  \
