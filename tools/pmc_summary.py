@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Average rocprofv3 --pmc counters per kernel from its sqlite output:
-    python tools/pmc_summary.py <results.db> [kernel-name-substring] [last-N-dispatches]"""
+    python tools/pmc_summary.py <results.db> [kernel-name-substring] [last-N-dispatches]
+When SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE were collected, a table follows: matrix-pipe utilisation =
+busy SIMD-cycles / (GUI-active cycles summed over the 8 XCDs / 8 * 1024 SIMDs), and the share of LDS cycles lost
+to bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)."""
 import collections
 import sqlite3
 import sys
@@ -24,3 +27,16 @@ for k, d in acc.items():
     print(f"{k[:120]}  ({n} dispatches, mean {sum(dur[k].values()) / n / 1e3:.1f} us under the profiler)")
     for c, v in sorted(d.items()):
         print(f"   {c:32s} {v / n:16.1f} per dispatch")
+
+rows = []
+for k, d in acc.items():
+    n = len(disp[k])
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("GRBM_GUI_ACTIVE"):
+        util = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * 128.0)
+        lds = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"] if d.get("SQ_LDS_IDX_ACTIVE") else 0.0
+        rows.append((sum(dur[k].values()), k, n, util, lds))
+if rows:
+    print("\nkernel | dispatches | mean us | MFMA busy / available | LDS cycles lost to bank conflicts")
+    for tot, k, n, util, lds in sorted(rows, reverse=True):
+        if util > 0 or lds > 0:
+            print(f"{k[:100]} | {n} | {tot / n / 1e3:.1f} | {util:.3f} | {lds:.3f}")
