@@ -62,6 +62,7 @@ class PackedTaps:
 
 
 SPLIT_MIN_CHANNELS = int(os.environ.get("VDMI_SPLIT_MIN_CHANNELS", "256"))
+SIDE_RES_CONV = os.environ.get("VDMI_SIDE_RES_CONV", "1") != "0"      # res_conv GEMMs of the wide layers on the side stream
 
 TAPS_3x3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 TAPS_4x4_S2 = [(ky - 1, kx - 1) for ky in range(4) for kx in range(4)]
@@ -80,10 +81,12 @@ def _fill_pass(p: TapPass, src0, c0, src1, c1, in_h, in_w, stride, taps, wdata, 
 
 
 class _Call:
-    __slots__ = ("fn", "args", "name")
+    """One launch.  side: it may run on the plan's side stream (nothing before the next `join` call reads its
+    output); join: the side stream's work must have finished before this launch."""
+    __slots__ = ("fn", "args", "name", "side", "join")
 
-    def __init__(self, fn, args, name):
-        self.fn, self.args, self.name = fn, args, name
+    def __init__(self, fn, args, name, side=False, join=False):
+        self.fn, self.args, self.name, self.side, self.join = fn, args, name, side, join
 
 
 class Plan:
@@ -105,10 +108,12 @@ class Plan:
         self.focus_in = torch.zeros(B, device=device, dtype=torch.uint8)     # focus-present mask, all False by default
         self.eps_out = torch.empty(B, u.out_dim, F, H, W, device=device, dtype=torch.float32)
         self.taps: Dict[str, torch.Tensor] = {}   # named intermediate activations (for tests)
-        self.join_index = None      # index of the first call that reads the time-embedding tables
         self._side = None
+        self._join_next = False     # the next launch added must wait for the side stream
         self._setup()
-        self.n_embed_calls = len(self.calls)
+        for c in self.calls:        # the time-embedding launches do not depend on the image: side stream
+            c.side = True
+        self._tables_pending = True
         if build:
             self._build()
 
@@ -118,10 +123,11 @@ class Plan:
         self.keep.append(t)
         return t
 
-    def _add(self, fn, args, name):
-        self.calls.append(_Call(fn, args, name))
+    def _add(self, fn, args, name, side=False):
+        self.calls.append(_Call(fn, args, name, side, self._join_next))
+        self._join_next = False
 
-    def _tapgemm(self, a: TapGemmArgs, name: str):
+    def _tapgemm(self, a: TapGemmArgs, name: str, side: bool = False):
         self.keep.append(a)
         lib = _lib.lib()
         # algorithmic work of the launch: 2*M*N*K over the positions computed (main pass + fused 1x1 pass)
@@ -132,7 +138,7 @@ class Plan:
         meta = {"kernel": f"tapgemm<epi={a.epilogue},bn={bn}>", "flops": 2.0 * m * a.n * k,
                 "bytes": 2.0 * (in_rows * (a.main.c0 + a.main.c1) / (4 if a.main.space_to_depth else 1)
                                 + m * a.n + a.n * k)}
-        self._add(lambda s, a=a: lib.vdmi_tapgemm(C.byref(a), s), meta, name)
+        self._add(lambda s, a=a: lib.vdmi_tapgemm(C.byref(a), s), meta, name, side)
 
     def _base_args(self, frames, grid_h, grid_w, out, n, epilogue, out_h=None, out_w=None) -> TapGemmArgs:
         a = TapGemmArgs()
@@ -146,8 +152,9 @@ class Plan:
     # -- layer builders ---------------------------------------------------------------------
     def _block(self, name, pk, srcs, h, w, gain, shift, bstride, res=None) -> torch.Tensor:
         """Block: conv3x3 + RMSNorm + scale/shift + SiLU, optionally + residual (res_conv or identity)."""
-        if self.join_index is None:
-            self.join_index = len(self.calls)
+        if self._tables_pending:    # first reader of the scale/shift tables
+            self._tables_pending = False
+            self._join_next = True
         frames = self.B * self.F
         (s0, c0), (s1, c1) = srcs[0], (srcs[1] if len(srcs) > 1 else (None, 0))
         w_pack, bias = pk
@@ -192,6 +199,8 @@ class Plan:
         a.tile_bn = 64
         self._tapgemm(a, name + ".conv")
         identity = res[1] if (res is not None and res[0] == "identity") else None
+        if res is not None and res[0] == "identity" and len(res) > 2 and res[2]:
+            self._join_next = True      # the residual was produced on the side stream
         out = self._buf(rows, n)
         meta = {"kernel": "rmsnorm_silu", "flops": 0.0, "bytes": 2.0 * rows * n * (3 if identity is not None else 2)}
         self._add(lambda s, raw=raw, out=out, identity=identity: lib.vdmi_rmsnorm_silu(
@@ -221,11 +230,28 @@ class Plan:
             g1, s1 = gain1, shift1
         else:
             g1, s1, bstride = rb["gamma1"], None, 0
+        early = None
+        if SIDE_RES_CONV and rb["wres"] is not None and "wt" not in rb and rb["w2"].tile_bn == 64:
+            # wide layers: res_conv(x) is its own 1x1 GEMM.  It depends on the block's input only, so it runs on the
+            # side stream beside block1 / block2 and comes back as the residual of block2's normalisation kernel.
+            if self._tables_pending:
+                self._tables_pending = False
+                self._join_next = True
+            frames, n = self.B * self.F, rb["w2"].n
+            (r0, rc0), (r1, rc1) = srcs[0], (srcs[1] if len(srcs) > 1 else (None, 0))
+            early = self._buf(frames * h * w, n)
+            b = self._base_args(frames, h, w, early, n, EPI_PLAIN)
+            _fill_pass(b.main, r0, rc0, r1, rc1, h, w, 1, [(0, 0)], rb["wres"].data)
+            b.bias = _ptr(rb["bres"])
+            b.tile_bn = rb["wres"].tile_bn
+            self._tapgemm(b, name + ".block2.res", side=True)
         hbuf = self._block(name + ".block1", (rb["w1"], rb["b1"]), srcs, h, w, g1, s1, bstride)
         cmid = rb["w1"].n
         if "wt" in rb:
             return self._resnet_temporal(name, rb, srcs, hbuf, cmid, h, w)
-        if rb["wres"] is not None:
+        if early is not None:
+            res = ("identity", early, True)
+        elif rb["wres"] is not None:
             res = ("conv", rb["wres"], rb["bres"], srcs)
         else:
             res = ("identity", srcs[0][0])
@@ -562,29 +588,29 @@ class Plan:
                 check(st, call.name)
 
     def run(self):
-        """Enqueue every launch (no host synchronisation).  The time-embedding kernels (the first calls) do not
-        depend on the image: they go to a side stream and are joined right before the first block that needs the
-        scale/shift tables, so they overlap the init conv and the first temporal attention - also inside a captured
-        HIP graph, where the fork / join becomes graph edges."""
+        """Enqueue every launch (no host synchronisation).  Launches flagged `side` (the time-embedding kernels, which
+        do not depend on the image; the res_conv GEMMs of the wide layers, which depend on the block input only) go
+        to a side stream; a launch flagged `join` first waits for it.  Inside a captured HIP graph the fork / join
+        become graph edges."""
         main = torch.cuda.current_stream(self.device)
-        s = main.cuda_stream
-        first, join = 0, self.join_index
-        if join is not None and join > self.n_embed_calls:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            self._side.wait_stream(main)
-            for call in self.calls[:self.n_embed_calls]:
-                st = call.fn(self._side.cuda_stream)
-                if st != 0:
-                    check(st, call.name)
-            first = self.n_embed_calls
-        for i in range(first, len(self.calls)):
-            if first and i == join:
+        forked = False
+        for call in self.calls:
+            if call.join and forked:
                 main.wait_stream(self._side)
-            call = self.calls[i]
-            st = call.fn(s)
+                forked = False
+            stream = main
+            if call.side:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                if not forked:
+                    self._side.wait_stream(main)
+                    forked = True
+                stream = self._side
+            st = call.fn(stream.cuda_stream)
             if st != 0:
                 check(st, call.name)
+        if forked:
+            main.wait_stream(self._side)
 
 
 class UnetEngine:

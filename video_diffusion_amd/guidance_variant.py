@@ -182,8 +182,9 @@ class GuidancePlan(Plan):
 
     def _gres(self, name, rb, srcs, h, w, use_time=True):
         """ResnetBlock of the variant (video_diffusion_guidance.py:345-388)."""
-        if self.join_index is None:
-            self.join_index = len(self.calls)
+        if self._tables_pending:    # first reader of the scale/shift tables: the side stream must be done
+            self._tables_pending = False
+            self._join_next = True
         rows = self.B * self.F * h * w
         n = rb["ts1"]["w"].n
         if rb["res"] is not None:
