@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void sla_context_kernel(const __bf16* __restri
         const int ksper = bkc / 16, ctn = cpad / 32;
         for (int ct = wave; ct < c / 32; ct += 4) {
             const int co = ct * 32 + l31;
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 acc = zero, acc1 = zero, acc2 = zero;
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk) {
                 const float* wr = w_out + (long long)co * hid + hd * 32 + 16 * sk + 8 * hf;
@@ -281,10 +282,12 @@ __global__ __launch_bounds__(256) void sla_context_kernel(const __bf16* __restri
                     wh[j] = hi;
                     wl[j] = f2bf(v - (float)hi);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[sk], wh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wl, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[sk], wh, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wl, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wh, acc, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc1[r] + acc2[r];
             // registers 4u..4u+3 hold d = 8u + 4 hf + {0..3} of channel co
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void sla_fold_kernel(const SlaArgs a, int c) {
         }
     for (int ct = wave; ct < CT; ct += 4) {
         const float* wr = wsl + out_chan(ct, l31) * 33;
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc = zero, acc1 = zero, acc2 = zero;
 #pragma unroll
         for (int sk = 0; sk < 2; ++sk) {
             bf16x8 wh, wl;
@@ -233,10 +234,12 @@ __global__ __launch_bounds__(256) void sla_fold_kernel(const SlaArgs a, int c) {
                 wh[j] = hi;
                 wl[j] = f2bf(v - (float)hi);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[sk], wh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wl, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[sk], wh, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wl, acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[sk], wh, acc, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc1[r] + acc2[r];
 #pragma unroll
         for (int sf = 0; sf < 2; ++sf) {
             bf16x8 o;
