@@ -798,6 +798,48 @@ def test_cfg3_cfg_eps_vs_reference():
     assert rel_err(eps.cpu(), g["eps_cfg2"]) < 2 * MODEL_TOL   # guidance doubles the difference term
 
 
+@pytest.mark.parametrize("parts", [2, 3])
+def test_split_plan_matches_single_plan(parts):
+    """A forward run as concurrent sub-batches (SplitPlan) is bit-identical to the single plan - conditioning,
+    null-condition mask, focus flags and frame context included - eagerly and when replayed from a HIP graph."""
+    from video_diffusion_amd.engine import Plan, SplitPlan
+    m = make_unet(salt=3, **TINY_COND).to(dev())
+    eng = m.engine()
+    eng.ensure_packed(dev())
+    B, Fr, H, L = 6, 4, 12, 5
+    one = Plan(eng, B, Fr, H, H, dev(), L=L, focus=True)
+    many = SplitPlan(eng, B, Fr, H, H, dev(), parts, L=L, focus=True)
+    assert len(many.calls) == parts * len(one.calls)
+    vals = dict(x_in=inp("split.x", (B, 3, Fr, H, H)), t_in=torch.tensor([0, 7, 130, 500, 998, 999]),
+                cond_in=inp("split.c", (B, 16)), null_mask=torch.tensor([0, 1, 0, 0, 1, 1], dtype=torch.uint8),
+                focus_in=torch.tensor([1, 0, 0, 1, 1, 0], dtype=torch.uint8),
+                ctx_in=inp("split.ctx", (B, L, one.ctx_in.shape[2])), ctx_keep=torch.tensor([1., 1, 0, 1, 0, 1]))
+    for pl in (one, many):
+        for k, v in vals.items():
+            getattr(pl, k).copy_(v.to(dev()))
+        pl.run_context()
+        pl.run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(one.eps_out).all()
+    assert torch.equal(one.eps_out, many.eps_out)
+    # replay from a graph with new inputs
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        many.run()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        many.run()
+    x2 = inp("split.x2", (B, 3, Fr, H, H)).to(dev())
+    one.x_in.copy_(x2)
+    many.x_in.copy_(x2)
+    one.run()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(one.eps_out, many.eps_out)
+
+
 def test_batch_independence_full_size():
     """Size-independent property at the benchmark batch: samples do not interact, so eps of a
     batch of 16 equals eps of its two halves, bit for bit."""

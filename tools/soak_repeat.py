@@ -20,7 +20,9 @@ plan.x_in.copy_(torch.randn_like(plan.x_in))
 plan.t_in.copy_(torch.arange(batch, device=dev) * (999 // max(1, batch - 1)))
 plan.run()
 torch.cuda.synchronize()
-bufs = [k for k in plan.keep if isinstance(k, torch.Tensor)] + [plan.eps_out]
+plans = getattr(plan, 'parts', [plan])
+bufs = [k for p in plans for k in p.keep if isinstance(k, torch.Tensor)] + [plan.eps_out]
+print('sub-plans:', len(plans))
 ref = [b.clone() for b in bufs]
 bad = 0
 for _ in range(n):

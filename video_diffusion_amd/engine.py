@@ -93,20 +93,21 @@ class Plan:
     """All launches of one Unet3D forward for a fixed (B, F, H, W)."""
 
     def __init__(self, eng: "UnetEngine", B: int, F: int, H: int, W: int, device, build: bool = True, L: int = 0,
-                 focus: bool = False):
+                 focus: bool = False, io: Optional[Dict[str, torch.Tensor]] = None):
         self.eng, self.B, self.F, self.H, self.W, self.device = eng, B, F, H, W, device
+        self._io = io or {}                   # input / output tensors handed in by an owner (views of its batch)
         self.focus_enabled = focus            # temporal attentions read the focus-present flags (focus_in)
         self.L = L                            # context tokens per sample of the frame cross-attention (0: layers skipped)
         self.calls: List[_Call] = []
         self.ctx_calls: List[_Call] = []      # key/value projection of the context: once per context, not per step
         self.keep: List[object] = []          # tensors / ctypes objects the calls point into
         u = eng.unet
-        self.x_in = torch.zeros(B, u.channels, F, H, W, device=device, dtype=torch.float32)
-        self.t_in = torch.zeros(B, device=device, dtype=torch.int64)
-        self.cond_in = torch.zeros(B, u.cond_dim, device=device, dtype=torch.float32) if u.has_cond else None
-        self.null_mask = torch.zeros(B, device=device, dtype=torch.uint8) if u.has_cond else None
-        self.focus_in = torch.zeros(B, device=device, dtype=torch.uint8)     # focus-present mask, all False by default
-        self.eps_out = torch.empty(B, u.out_dim, F, H, W, device=device, dtype=torch.float32)
+        self.x_in = self._io_tensor("x_in", (B, u.channels, F, H, W), torch.float32)
+        self.t_in = self._io_tensor("t_in", (B,), torch.int64)
+        self.cond_in = self._io_tensor("cond_in", (B, u.cond_dim), torch.float32) if u.has_cond else None
+        self.null_mask = self._io_tensor("null_mask", (B,), torch.uint8) if u.has_cond else None
+        self.focus_in = self._io_tensor("focus_in", (B,), torch.uint8)       # focus-present mask, all False by default
+        self.eps_out = self._io_tensor("eps_out", (B, u.out_dim, F, H, W), torch.float32)
         self.taps: Dict[str, torch.Tensor] = {}   # named intermediate activations (for tests)
         self._side = None
         self._join_next = False     # the next launch added must wait for the side stream
@@ -118,6 +119,14 @@ class Plan:
             self._build()
 
     # -- buffer / call helpers -------------------------------------------------------------
+    def _io_tensor(self, name, shape, dtype, fill=0) -> torch.Tensor:
+        t = self._io.get(name)
+        if t is None:
+            return torch.full(shape, fill, device=self.device, dtype=dtype)
+        if tuple(t.shape) != tuple(shape) or t.dtype != dtype or not t.is_contiguous():
+            raise _lib.VdmiError(f"plan tensor {name}: expected contiguous {tuple(shape)} {dtype}, got {tuple(t.shape)} {t.dtype}")
+        return t
+
     def _buf(self, rows: int, ch: int) -> torch.Tensor:
         t = torch.empty(rows, ch, device=self.device, dtype=torch.bfloat16)
         self.keep.append(t)
@@ -402,8 +411,8 @@ class Plan:
         X = self.eng.packed["xattn"]
         B, L, D, dev = self.B, self.L, X["ctx_dim"], self.device
         nl, hid = X["nl"], X["hid"]
-        self.ctx_in = torch.zeros(B, L, D, device=dev, dtype=torch.float32)
-        self.ctx_keep = torch.ones(B, device=dev, dtype=torch.float32)
+        self.ctx_in = self._io_tensor("ctx_in", (B, L, D), torch.float32)
+        self.ctx_keep = self._io_tensor("ctx_keep", (B,), torch.float32, fill=1)
         ctx_rows = self._buf(B * L, D)
         kv_rows = self._buf(B * L, nl * 2 * hid)
         self.kv_layer_elems = lib.vdmi_xattn_kv_elems(1, B, L, hid // 32)
@@ -587,11 +596,11 @@ class Plan:
             if st != 0:
                 check(st, call.name)
 
-    def run(self):
+    def run(self, fork: bool = True):
         """Enqueue every launch (no host synchronisation).  Launches flagged `side` (the time-embedding kernels, which
         do not depend on the image; the res_conv GEMMs of the wide layers, which depend on the block input only) go
         to a side stream; a launch flagged `join` first waits for it.  Inside a captured HIP graph the fork / join
-        become graph edges."""
+        become graph edges.  fork=False keeps every launch on the current stream, in order."""
         main = torch.cuda.current_stream(self.device)
         forked = False
         for call in self.calls:
@@ -599,7 +608,7 @@ class Plan:
                 main.wait_stream(self._side)
                 forked = False
             stream = main
-            if call.side:
+            if call.side and fork:
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=self.device)
                 if not forked:
@@ -611,6 +620,75 @@ class Plan:
                 check(st, call.name)
         if forked:
             main.wait_stream(self._side)
+
+
+BATCH_PARTS = int(os.environ.get("VDMI_BATCH_PARTS", "2"))
+BATCH_PARTS_MIN = int(os.environ.get("VDMI_BATCH_PARTS_MIN", "4"))     # smallest batch that is split
+
+
+def batch_parts(B: int) -> int:
+    """Number of independent sub-batches a forward of B samples is run as (1: not split)."""
+    n = BATCH_PARTS
+    return n if n > 1 and B >= BATCH_PARTS_MIN and B % n == 0 else 1
+
+
+class SplitPlan:
+    """One forward run as `parts` independent sub-batch plans on concurrent HIP streams.
+
+    Samples never interact in Unet3D (reference vdp.py:756-831: every norm, attention and conv is per sample), so the
+    result is the same bit for bit; the point is occupancy: between two dependent launches of one stream the device
+    idles for a few microseconds, the tail of every launch leaves compute units empty, and the deep, small-image
+    layers launch too few workgroups for 256 of them - a second stream fills all three.  The owner sees one set of
+    input / output tensors (x_in, t_in, eps_out ...); the sub-plans work on views of them.  Under graph capture the
+    fork / join become graph edges.  The sub-plans keep all their launches on their own stream (a fork from an already
+    forked stream does not survive graph capture), and the streams stay within the four hardware queues of a process:
+    with more, HIP serialises streams and the overlap is lost."""
+
+    def __init__(self, eng: "UnetEngine", B, F, H, W, device, parts: int, L: int = 0, focus: bool = False):
+        if B % parts:
+            raise ValueError(f"batch {B} does not split into {parts} equal parts")
+        u = eng.unet
+        self.eng, self.B, self.F, self.H, self.W, self.device, self.L = eng, B, F, H, W, device, L
+        self.focus_enabled = focus
+        f32 = dict(device=device, dtype=torch.float32)
+        self.x_in = torch.zeros(B, u.channels, F, H, W, **f32)
+        self.t_in = torch.zeros(B, device=device, dtype=torch.int64)
+        self.cond_in = torch.zeros(B, u.cond_dim, **f32) if u.has_cond else None
+        self.null_mask = torch.zeros(B, device=device, dtype=torch.uint8) if u.has_cond else None
+        self.focus_in = torch.zeros(B, device=device, dtype=torch.uint8)
+        self.eps_out = torch.empty(B, u.out_dim, F, H, W, **f32)
+        names = ["x_in", "t_in", "cond_in", "null_mask", "focus_in", "eps_out"]
+        if L:
+            self.ctx_in = torch.zeros(B, L, eng.packed["xattn"]["ctx_dim"], **f32)
+            self.ctx_keep = torch.ones(B, **f32)
+            names += ["ctx_in", "ctx_keep"]
+        n = B // parts
+        self.parts: List[Plan] = []
+        for i in range(parts):
+            io = {k: getattr(self, k)[i * n:(i + 1) * n] for k in names if getattr(self, k) is not None}
+            self.parts.append(eng.plan_class(eng, n, F, H, W, device, L=L, focus=focus, io=io))
+        self._streams = [torch.cuda.Stream(device=device) for _ in range(parts)]
+        self.calls = [c for p in self.parts for c in p.calls]              # flat list, for per-launch timing
+        self.ctx_calls = [c for p in self.parts for c in p.ctx_calls]
+
+    def _fan_out(self, fn):
+        main = torch.cuda.current_stream(self.device)
+        for p, s in zip(self.parts, self._streams):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                fn(p)
+        for s in self._streams:
+            main.wait_stream(s)
+
+    def run_context(self):
+        self._fan_out(lambda p: p.run_context())
+
+    def run(self, fork: bool = True):
+        if fork:
+            self._fan_out(lambda p: p.run(fork=False))
+        else:
+            for p in self.parts:
+                p.run(fork=False)
 
 
 class UnetEngine:
@@ -894,7 +972,11 @@ class UnetEngine:
         self.ensure_packed(device)
         key = (B, F, H, W, str(device), L, focus)
         if key not in self._plans:
-            self._plans[key] = self.plan_class(self, B, F, H, W, device, L=L, focus=focus)
+            parts = batch_parts(B)
+            if parts > 1:
+                self._plans[key] = SplitPlan(self, B, F, H, W, device, parts, L=L, focus=focus)
+            else:
+                self._plans[key] = self.plan_class(self, B, F, H, W, device, L=L, focus=focus)
         return self._plans[key]
 
     @torch.no_grad()
