@@ -89,3 +89,21 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.vdmi_tapgemm_tile(_lib.EPI_NORM_SILU, 4096, C.byref(bn), C.byref(bkc)) == -2
     with pytest.raises(_lib.VdmiError):
         _lib.check(-2, "probe")
+
+
+def test_batch_split_policy():
+    """Host logic of the two-stream forward: which batches are run as sub-batches, and the launch flags of a plan."""
+    from video_diffusion_amd import engine
+    assert engine.batch_parts(16) == 2 and engine.batch_parts(32) == 2 and engine.batch_parts(4) == 2
+    assert engine.batch_parts(1) == 1 and engine.batch_parts(2) == 1 and engine.batch_parts(3) == 1
+    assert engine.batch_parts(7) == 1      # does not divide
+    old = engine.BATCH_PARTS
+    try:
+        engine.BATCH_PARTS = 1
+        assert engine.batch_parts(16) == 1
+        engine.BATCH_PARTS = 4
+        assert engine.batch_parts(16) == 4 and engine.batch_parts(6) == 1
+    finally:
+        engine.BATCH_PARTS = old
+    c = engine._Call(lambda s: 0, None, "x", side=True)
+    assert c.side and not c.join
