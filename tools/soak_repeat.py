@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Repeatability soak: replay the captured denoise step N times on fixed inputs and compare every activation
 buffer bit for bit with the first run (catches races between the plan's main and side streams).
-    python tools/soak_repeat.py [N] [batch]"""
+    python tools/soak_repeat.py [N] [batch] [plain|cond]        cond: condition vector, frame context and focus flags on"""
 import os
 import sys
 
@@ -14,8 +14,19 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-m = Unet3D(dim=64, dim_mults=(1, 2, 4, 8), channels=1).to(dev).eval()
-plan = m.engine().plan(batch, 10, 64, 64, dev)
+cond = len(sys.argv) > 3 and sys.argv[3] == "cond"
+if cond:
+    m = Unet3D(dim=64, dim_mults=(1, 2, 4, 8), channels=4, cond_dim=64).to(dev).eval()
+    plan = m.engine().plan(batch, 10, 32, 32, dev, L=256, focus=True)
+    plan.cond_in.copy_(torch.randn_like(plan.cond_in))
+    plan.null_mask.copy_((torch.arange(batch, device=dev) % 3 == 0).to(torch.uint8))
+    plan.focus_in.copy_((torch.arange(batch, device=dev) % 2).to(torch.uint8))
+    plan.ctx_in.copy_(torch.randn_like(plan.ctx_in))
+    plan.ctx_keep.copy_((torch.arange(batch, device=dev) % 4 != 1).float())
+    plan.run_context()
+else:
+    m = Unet3D(dim=64, dim_mults=(1, 2, 4, 8), channels=1).to(dev).eval()
+    plan = m.engine().plan(batch, 10, 64, 64, dev)
 plan.x_in.copy_(torch.randn_like(plan.x_in))
 plan.t_in.copy_(torch.arange(batch, device=dev) * (999 // max(1, batch - 1)))
 plan.run()
