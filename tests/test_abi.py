@@ -96,13 +96,13 @@ def test_batch_split_policy():
     from video_diffusion_amd import engine
     assert engine.batch_parts(16) == 2 and engine.batch_parts(32) == 2 and engine.batch_parts(4) == 2
     assert engine.batch_parts(1) == 1 and engine.batch_parts(2) == 1 and engine.batch_parts(3) == 1
-    assert engine.batch_parts(7) == 1      # does not divide
+    assert engine.batch_parts(7) == 2      # 4 + 3
     old = engine.BATCH_PARTS
     try:
         engine.BATCH_PARTS = 1
         assert engine.batch_parts(16) == 1
         engine.BATCH_PARTS = 4
-        assert engine.batch_parts(16) == 4 and engine.batch_parts(6) == 1
+        assert engine.batch_parts(16) == 4 and engine.batch_parts(6) == 1 and engine.batch_parts(9) == 4
     finally:
         engine.BATCH_PARTS = old
     c = engine._Call(lambda s: 0, None, "x", side=True)

@@ -798,7 +798,7 @@ def test_cfg3_cfg_eps_vs_reference():
     assert rel_err(eps.cpu(), g["eps_cfg2"]) < 2 * MODEL_TOL   # guidance doubles the difference term
 
 
-@pytest.mark.parametrize("parts", [2, 3])
+@pytest.mark.parametrize("parts", [2, 3, 4])
 def test_split_plan_matches_single_plan(parts):
     """A forward run as concurrent sub-batches (SplitPlan) is bit-identical to the single plan - conditioning,
     null-condition mask, focus flags and frame context included - eagerly and when replayed from a HIP graph."""
@@ -809,7 +809,7 @@ def test_split_plan_matches_single_plan(parts):
     B, Fr, H, L = 6, 4, 12, 5
     one = Plan(eng, B, Fr, H, H, dev(), L=L, focus=True)
     many = SplitPlan(eng, B, Fr, H, H, dev(), parts, L=L, focus=True)
-    assert len(many.calls) == parts * len(one.calls)
+    assert len(many.calls) == parts * len(one.calls) and sum(p.B for p in many.parts) == B      # 4 parts: 2+2+1+1
     vals = dict(x_in=inp("split.x", (B, 3, Fr, H, H)), t_in=torch.tensor([0, 7, 130, 500, 998, 999]),
                 cond_in=inp("split.c", (B, 16)), null_mask=torch.tensor([0, 1, 0, 0, 1, 1], dtype=torch.uint8),
                 focus_in=torch.tensor([1, 0, 0, 1, 1, 0], dtype=torch.uint8),

@@ -629,7 +629,7 @@ BATCH_PARTS_MIN = int(os.environ.get("VDMI_BATCH_PARTS_MIN", "4"))     # smalles
 def batch_parts(B: int) -> int:
     """Number of independent sub-batches a forward of B samples is run as (1: not split)."""
     n = BATCH_PARTS
-    return n if n > 1 and B >= BATCH_PARTS_MIN and B % n == 0 else 1
+    return n if n > 1 and B >= BATCH_PARTS_MIN and B >= 2 * n else 1
 
 
 class SplitPlan:
@@ -645,8 +645,8 @@ class SplitPlan:
     with more, HIP serialises streams and the overlap is lost."""
 
     def __init__(self, eng: "UnetEngine", B, F, H, W, device, parts: int, L: int = 0, focus: bool = False):
-        if B % parts:
-            raise ValueError(f"batch {B} does not split into {parts} equal parts")
+        if parts < 1 or B < parts:
+            raise ValueError(f"batch {B} does not split into {parts} parts")
         u = eng.unet
         self.eng, self.B, self.F, self.H, self.W, self.device, self.L = eng, B, F, H, W, device, L
         self.focus_enabled = focus
@@ -662,11 +662,13 @@ class SplitPlan:
             self.ctx_in = torch.zeros(B, L, eng.packed["xattn"]["ctx_dim"], **f32)
             self.ctx_keep = torch.ones(B, **f32)
             names += ["ctx_in", "ctx_keep"]
-        n = B // parts
         self.parts: List[Plan] = []
-        for i in range(parts):
-            io = {k: getattr(self, k)[i * n:(i + 1) * n] for k in names if getattr(self, k) is not None}
+        start = 0
+        for i in range(parts):       # near-equal parts; the first B % parts take one sample more
+            n = B // parts + (1 if i < B % parts else 0)
+            io = {k: getattr(self, k)[start:start + n] for k in names if getattr(self, k) is not None}
             self.parts.append(eng.plan_class(eng, n, F, H, W, device, L=L, focus=focus, io=io))
+            start += n
         self._streams = [torch.cuda.Stream(device=device) for _ in range(parts)]
         self.calls = [c for p in self.parts for c in p.calls]              # flat list, for per-launch timing
         self.ctx_calls = [c for p in self.parts for c in p.ctx_calls]
