@@ -859,6 +859,7 @@ def test_batch_independence_full_size():
     ("odd_hw", dict(dim=32, dim_mults=(1, 2), channels=1), (3, 1, 5, 6, 10)),                # ragged tiles, odd batch
     ("three_levels_b1", dict(dim=32, dim_mults=(1, 2, 4), channels=4), (1, 4, 3, 12, 12)),
     ("no_sla", dict(dim=32, dim_mults=(1, 2), channels=3, use_sparse_linear_attn=False), (2, 3, 4, 8, 8)),
+    ("batch5_split_3_2", dict(dim=32, dim_mults=(1, 2), channels=3), (5, 3, 4, 8, 8)),         # unequal sub-batches on two streams
     ("k5_out6", dict(dim=32, dim_mults=(1, 2), channels=3, init_kernel_size=5, out_dim=6), (2, 3, 4, 8, 8)),
 ])
 def test_unusual_shapes_vs_oracle(name, kw, shape):
