@@ -276,6 +276,14 @@ int vdmi_block_scale_shift(const float* emb_silu, int b, int emb_dim, const floa
                            const float* gamma_all, const int32_t* block_offsets, const int32_t* block_channels,
                            int nblocks, int half_total, float* gain, float* shift, vdmi_stream stream);
 
+/* Scale/shift tables of a sampling loop: the time embedding and every ResnetBlock.mlp (vdp.py:339-351, 432-448,
+ * 651-656) depend on the timestep only when there is no condition vector, so a loop computes gain/shift for all T
+ * timesteps once (vdmi_time_embed + vdmi_block_scale_shift with b = T) and each step copies its rows:
+ * gain[i][:] = gain_table[t[i]][:], shift likewise.  Tables float [T][cols], t int64 [b] with 0 <= t[i] < T
+ * (rows outside are left untouched), outputs float [b][cols]; cols a multiple of 4. */
+int vdmi_gather_scale_shift(const float* gain_table, const float* shift_table, int T, const int64_t* t, int b, int cols,
+                            float* gain, float* shift, vdmi_stream stream);
+
 /* HOST. RelativePositionBias bucket ids (vdp.py:286-304), int32 [n][n], entry (i,j) = query i, key j. */
 int vdmi_relpos_buckets(int n, int num_buckets, int max_distance, int32_t* out);
 

@@ -87,6 +87,45 @@ def test_time_mlp_and_tables(tiny):
     assert rel_err(L.plan.shift[:, off:off + n].cpu(), sh) < 1e-5
 
 
+def test_timestep_tables_match_per_step_kernels(tiny):
+    """A sampling-loop plan copies its scale/shift rows from the engine's tables of all timesteps; rows are
+    bit-identical to what the per-step time-embedding kernels produce, and so is eps."""
+    from video_diffusion_amd import _lib
+    from video_diffusion_amd.engine import Plan
+    m = tiny["m"].to(dev())
+    eng, T, B, Fr, H = m.engine(), 50, 3, tiny["F"], tiny["H"]
+    eng.ensure_packed(dev())
+    per_step = Plan(eng, B, Fr, H, H, dev())
+    tabled = Plan(eng, B, Fr, H, H, dev(), time_table=T)
+    assert len(tabled.calls) < len(per_step.calls)
+    x, t = inp("tables.x", (B, 3, Fr, H, H)).to(dev()), torch.tensor([0, 17, T - 1], device=dev())
+    for pl in (per_step, tabled):
+        pl.x_in.copy_(x)
+        pl.t_in.copy_(t)
+        pl.run()
+    torch.cuda.synchronize()
+    assert torch.equal(per_step.gain, tabled.gain) and torch.equal(per_step.shift, tabled.shift)
+    assert torch.equal(per_step.eps_out, tabled.eps_out)
+    # rows of a timestep outside the table are left as they were; bad shapes are refused
+    gt, st = eng.time_tables(T, dev())
+    cols = gt.shape[1]
+    gain, shift = torch.full((2, cols), 7.0, device=dev()), torch.full((2, cols), -7.0, device=dev())
+    tt = torch.tensor([T, 4], device=dev())
+    s = torch.cuda.current_stream().cuda_stream
+    rc = _lib.lib().vdmi_gather_scale_shift(gt.data_ptr(), st.data_ptr(), T, tt.data_ptr(), 2, cols, gain.data_ptr(),
+                                            shift.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert rc == 0 and (gain[0] == 7.0).all() and (shift[0] == -7.0).all()
+    assert torch.equal(gain[1], gt[4]) and torch.equal(shift[1], st[4])
+    assert _lib.lib().vdmi_gather_scale_shift(gt.data_ptr(), st.data_ptr(), T, tt.data_ptr(), 2, cols - 1,
+                                              gain.data_ptr(), shift.data_ptr(), s) != 0
+    # a model with a condition vector has no such tables: its plans keep the per-step kernels
+    mc = make_unet(salt=3, **TINY_COND).to(dev())
+    with pytest.raises(_lib.VdmiError):
+        mc.engine().time_tables(T, dev())
+    assert mc.engine().plan(2, Fr, H, H, dev(), time_table=T).time_table == 0
+
+
 def test_relpos_bias_table(tiny):
     L, g = tiny["L"], tiny["g"]
     assert torch.allclose(L.plan.pos_bias.cpu(), g["relpos_bias"], atol=0, rtol=0)

@@ -94,6 +94,8 @@ _SIGNATURES = {
     "vdmi_final_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "vdmi_time_embed": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] +
                         [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdmi_gather_scale_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
     "vdmi_block_scale_shift": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 +
                                [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdmi_relpos_buckets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),

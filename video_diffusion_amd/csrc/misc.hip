@@ -567,6 +567,21 @@ extern "C" int vdmi_ddpm_step(const float* x, const float* eps, const float* z, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-step rows of the precomputed scale/shift tables of a sampling loop (see vdmi_gather_scale_shift).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_scale_shift_kernel(const float* __restrict__ gt, const float* __restrict__ st,
+                                                                 int T, const long long* __restrict__ t, int cols,
+                                                                 float* __restrict__ gain, float* __restrict__ shift) {
+    const int b = blockIdx.y;
+    const long long row = t[b];
+    if (row < 0 || row >= T) return;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= cols) return;
+    *reinterpret_cast<f32x4*>(gain + (long long)b * cols + c) = *reinterpret_cast<const f32x4*>(gt + row * cols + c);
+    *reinterpret_cast<f32x4*>(shift + (long long)b * cols + c) = *reinterpret_cast<const f32x4*>(st + row * cols + c);
+}
+
+// ------------------------------------------------------------------------------------------
 // RMSNorm over channels + scale/shift + SiLU (+ identity residual) of channels-last rows: the tail of
 // Block.forward (reference vdp.py:391-427) and the ResnetBlock residual add (vdp.py:452) for wide
 // layers whose convolution is split over output-channel tiles.
@@ -833,4 +848,16 @@ extern "C" int vdmi_rmsnorm_silu(const void* x, int ldx, void* out, int ldo, int
     VDMI_RMS_CASE(64, 3)    // 1536
 #undef VDMI_RMS_CASE
     return VDMI_E_SHAPE;
+}
+
+extern "C" int vdmi_gather_scale_shift(const float* gain_table, const float* shift_table, int T, const int64_t* t, int b,
+                                       int cols, float* gain, float* shift, vdmi_stream stream) {
+    if (!gain_table || !shift_table || !t || !gain || !shift) return VDMI_E_ARG;
+    if (T <= 0 || b <= 0 || b > 65535 || cols <= 0 || cols % 4) return VDMI_E_SHAPE;
+    if (!aligned16(gain_table) || !aligned16(shift_table) || !aligned16(gain) || !aligned16(shift)) return VDMI_E_ALIGN;
+    hipLaunchKernelGGL(gather_scale_shift_kernel, dim3((unsigned)((cols / 4 + 255) / 256), (unsigned)b), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), gain_table, shift_table, T,
+                       reinterpret_cast<const long long*>(t), cols, gain, shift);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
 }

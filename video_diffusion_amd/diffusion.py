@@ -188,7 +188,8 @@ class GaussianDiffusion(nn.Module):
         if key in self._graphs:
             return self._graphs[key]
         B, Cc, Fr, H, W = shape
-        plan = fn.engine().plan(B, Fr, H, W, device)
+        # every step of the loop uses t in [0, num_timesteps): scale/shift rows come from the engine's timestep tables
+        plan = fn.engine().plan(B, Fr, H, W, device, time_table=self.num_timesteps)
         z = torch.zeros(shape, device=device, dtype=torch.float32) if self.noise_source == "torch" else None
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
 
@@ -271,7 +272,7 @@ class GaussianDiffusion(nn.Module):
         rep = 2 if guided else 1
         _, Cc, Fr, H, W = shape
         eng = fn.engine()
-        plan = eng.plan(rep * B, Fr, H, W, device, feats.shape[1])
+        plan = eng.plan(rep * B, Fr, H, W, device, feats.shape[1], time_table=self.num_timesteps)
         plan.ctx_in.copy_(feats.repeat(rep, 1, 1))
         plan.ctx_keep.fill_(1)
         if guided:

@@ -62,6 +62,7 @@ class PackedTaps:
 
 
 SPLIT_MIN_CHANNELS = int(os.environ.get("VDMI_SPLIT_MIN_CHANNELS", "256"))
+TIME_TABLES = os.environ.get("VDMI_TIME_TABLES", "1") != "0"          # sampling loops copy scale/shift rows from per-timestep tables
 SIDE_RES_CONV = os.environ.get("VDMI_SIDE_RES_CONV", "1") != "0"      # res_conv GEMMs of the wide layers on the side stream
 
 TAPS_3x3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
@@ -93,8 +94,9 @@ class Plan:
     """All launches of one Unet3D forward for a fixed (B, F, H, W)."""
 
     def __init__(self, eng: "UnetEngine", B: int, F: int, H: int, W: int, device, build: bool = True, L: int = 0,
-                 focus: bool = False, io: Optional[Dict[str, torch.Tensor]] = None):
+                 focus: bool = False, io: Optional[Dict[str, torch.Tensor]] = None, time_table: int = 0):
         self.eng, self.B, self.F, self.H, self.W, self.device = eng, B, F, H, W, device
+        self.time_table = time_table          # > 0: scale/shift rows come from the engine's table of that many timesteps
         self._io = io or {}                   # input / output tensors handed in by an owner (views of its batch)
         self.focus_enabled = focus            # temporal attentions read the focus-present flags (focus_in)
         self.L = L                            # context tokens per sample of the frame cross-attention (0: layers skipped)
@@ -504,6 +506,13 @@ class Plan:
         half_total = P["half_total"]
         self.gain = torch.empty(B, half_total, device=dev, dtype=torch.float32)
         self.shift = torch.empty(B, half_total, device=dev, dtype=torch.float32)
+        if self.time_table:
+            # a sampling loop without a condition vector: the tables of all timesteps exist already, copy this step's rows
+            gt, st = eng.time_tables(self.time_table, dev)
+            self._add(lambda s: lib.vdmi_gather_scale_shift(
+                gt.data_ptr(), st.data_ptr(), self.time_table, self.t_in.data_ptr(), B, half_total,
+                self.gain.data_ptr(), self.shift.data_ptr(), s), None, "gather_scale_shift")
+            return
         tm = P["time"]
         self._add(lambda s: lib.vdmi_time_embed(
             self.t_in.data_ptr(), B, u.dim, tm["w1"].data_ptr(), tm["b1"].data_ptr(), tm["w2"].data_ptr(),
@@ -644,7 +653,8 @@ class SplitPlan:
     forked stream does not survive graph capture), and the streams stay within the four hardware queues of a process:
     with more, HIP serialises streams and the overlap is lost."""
 
-    def __init__(self, eng: "UnetEngine", B, F, H, W, device, parts: int, L: int = 0, focus: bool = False):
+    def __init__(self, eng: "UnetEngine", B, F, H, W, device, parts: int, L: int = 0, focus: bool = False,
+                 time_table: int = 0):
         if parts < 1 or B < parts:
             raise ValueError(f"batch {B} does not split into {parts} parts")
         u = eng.unet
@@ -667,7 +677,7 @@ class SplitPlan:
         for i in range(parts):       # near-equal parts; the first B % parts take one sample more
             n = B // parts + (1 if i < B % parts else 0)
             io = {k: getattr(self, k)[start:start + n] for k in names if getattr(self, k) is not None}
-            self.parts.append(eng.plan_class(eng, n, F, H, W, device, L=L, focus=focus, io=io))
+            self.parts.append(eng.plan_class(eng, n, F, H, W, device, L=L, focus=focus, io=io, time_table=time_table))
             start += n
         self._streams = [torch.cuda.Stream(device=device) for _ in range(parts)]
         self.calls = [c for p in self.parts for c in p.calls]              # flat list, for per-launch timing
@@ -967,18 +977,49 @@ class UnetEngine:
         return self._const_cache[key]
 
     # -- execution -------------------------------------------------------------------------------
-    def plan(self, B, F, H, W, device, L: int = 0, focus: bool = False) -> Plan:
+    def time_tables(self, T: int, device):
+        """gain / shift rows of every timestep 0..T-1, float [T][half_total] each: the same two kernels a step would
+        run, once over b = T rows (reference vdp.py:339-351, 432-448, 651-656; only valid without a condition vector)."""
+        self.ensure_packed(device)
+        key = ("time_tables", T, str(device))
+        if key not in self._const_cache:
+            if self.unet.has_cond:
+                raise _lib.VdmiError("timestep tables need a model without a condition vector")
+            lib, P, u = _lib.lib(), self.packed, self.unet
+            ed, half_total, tm = P["emb_dim"], P["half_total"], P["time"]
+            t_all = torch.arange(T, device=device, dtype=torch.int64)
+            silu = torch.empty(T, ed, device=device, dtype=torch.float32)
+            raw = torch.empty(T, ed, device=device, dtype=torch.float32)
+            gain = torch.empty(T, half_total, device=device, dtype=torch.float32)
+            shift = torch.empty(T, half_total, device=device, dtype=torch.float32)
+            s = _stream()
+            check(lib.vdmi_time_embed(t_all.data_ptr(), T, u.dim, tm["w1"].data_ptr(), tm["b1"].data_ptr(),
+                                      tm["w2"].data_ptr(), tm["b2"].data_ptr(), None, None, None, 0,
+                                      silu.data_ptr(), raw.data_ptr(), s), "vdmi_time_embed")
+            check(lib.vdmi_block_scale_shift(silu.data_ptr(), T, ed, P["w_all"].data_ptr(), P["b_all"].data_ptr(),
+                                             P["gamma_all"].data_ptr(), P["blk_off"].data_ptr(), P["blk_ch"].data_ptr(),
+                                             P["nblocks"], half_total, gain.data_ptr(), shift.data_ptr(), s),
+                  "vdmi_block_scale_shift")
+            torch.cuda.current_stream(device).synchronize()      # t_all, silu, raw go out of scope
+            self._const_cache[key] = (gain, shift)
+        return self._const_cache[key]
+
+    def plan(self, B, F, H, W, device, L: int = 0, focus: bool = False, time_table: int = 0) -> Plan:
         """L > 0: with the frame cross-attention layers, for contexts of L tokens per sample.  focus: the temporal
         attentions honour the focus-present flags (a separate plan: without them the fused kernel folds bias and
-        mask into its score product)."""
+        mask into its score product).  time_table = T > 0 (sampling loops; ignored for models with a condition vector):
+        the per-step time-embedding launches are replaced by a row copy from the tables of all T timesteps, so
+        t_in must stay within [0, T)."""
         self.ensure_packed(device)
-        key = (B, F, H, W, str(device), L, focus)
+        if self.unet.has_cond or not TIME_TABLES:
+            time_table = 0
+        key = (B, F, H, W, str(device), L, focus, time_table)
         if key not in self._plans:
             parts = batch_parts(B)
             if parts > 1:
-                self._plans[key] = SplitPlan(self, B, F, H, W, device, parts, L=L, focus=focus)
+                self._plans[key] = SplitPlan(self, B, F, H, W, device, parts, L=L, focus=focus, time_table=time_table)
             else:
-                self._plans[key] = self.plan_class(self, B, F, H, W, device, L=L, focus=focus)
+                self._plans[key] = self.plan_class(self, B, F, H, W, device, L=L, focus=focus, time_table=time_table)
         return self._plans[key]
 
     @torch.no_grad()
