@@ -205,6 +205,15 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": dom["launches_per_step"],
                     "videos_per_launch": B // parts,
                     "algorithmic_gflop_per_launch": round(dom["flops_per_step"] / dom["launches_per_step"] / 1e9, 2)}
+        # beside the nominal peak: what an operand-free MFMA loop reaches on this device (tools/peak_probe.hip)
+        ppath = os.path.join(ROOT, "profiles", "peak_probe.json")
+        if os.path.exists(ppath):
+            try:
+                measured = max(json.load(open(ppath))["mfma_bf16_tflops"].values())
+                roofline["peak_measured"] = measured
+                roofline["frac_of_measured"] = round(achieved / measured, 4)
+            except Exception:
+                pass
         # the whole step on the same scale: all matrix-core work of a step over the step time of the timed loop
         # (the sub-batch streams overlap there, so this can exceed what any one launch reaches on its own)
         step_tflops = sum(c["flops_per_step"] for c in classes.values()) / (elapsed / args.steps) / 1e12
