@@ -40,6 +40,11 @@
 #define VDMI_STAMP_ADD(ptr, slot, val) do { } while (0)
 #endif
 
+// steps ahead a weight tile is requested in the deep-prefetch kernels (register sets = this + 1)
+#ifndef VDMI_WPD
+#define VDMI_WPD 3
+#endif
+
 namespace {
 
 struct PassDev {
@@ -103,7 +108,7 @@ constexpr int patch_lb(int bm, int nt) {
     return bm >= 256 ? (13 * 256 + nt - 1) / nt : (bm >= 64 ? (12 * 256 + nt - 1) / nt : 2);
 }
 
-template <int BM, int BN, int WM, int WN, int BKC, bool STATS, class Pro>
+template <int BM, int BN, int WM, int WN, int BKC, bool STATS, bool DEEP, class Pro>
 __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32][WM / 32], __bf16* wbuf,
                                          __bf16* patch, float* stats, int frame, int ty, int tx, int ltw,
                                          int nt, int tid, float ln_eps, Pro&& after_first_loads,
@@ -135,11 +140,15 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     const int ntp = g.phases > 1 ? g.ntaps / g.phases : g.ntaps, tap0 = phase * ntp;   // this phase's taps
     wg += phase * g.w_phase_stride;
 
-    bf16x8 wreg[WP];
-    auto load_w = [&](int s) {
+    // weight tiles travel global -> registers -> LDS.  DEEP: three register sets, so the tile of step s + 2 is
+    // requested while step s computes (one step of MFMAs is shorter than an L2 round trip when few workgroups share
+    // a CU); otherwise one set, refilled for step s + 1 as soon as step s's tile is in LDS.
+    constexpr int PD = DEEP ? VDMI_WPD : 1, RING = DEEP ? PD + 1 : 1;
+    bf16x8 wreg[RING][WP];
+    auto load_w = [&](bf16x8 (&dst)[WP], int s) {
         const __bf16* p = wg + (long long)s * g.wtile_all;
 #pragma unroll
-        for (int k = 0; k < WP; ++k) wreg[k] = *reinterpret_cast<const bf16x8*>(p + (tid + k * NT) * 8);
+        for (int k = 0; k < WP; ++k) dst[k] = *reinterpret_cast<const bf16x8*>(p + (tid + k * NT) * 8);
     };
 
     float s1[KMAX], s2[KMAX];
@@ -150,7 +159,12 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
 
     const int nsteps = g.nch * ntp;
     const int total = g.ph * g.pw * PPR;
-    load_w(0);
+    load_w(wreg[0], 0);
+    if constexpr (DEEP) {
+#pragma unroll
+        for (int u = 1; u < PD; ++u)
+            if (u < nsteps) load_w(wreg[u], u);
+    }
 
     // ---- patch staging, software pipelined: the loads of chunk c+1 are in flight during chunk c's MFMAs
     constexpr int LB = patch_lb(BM, NT);
@@ -235,83 +249,93 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     patch_prefetch(0);
     after_first_loads();   // per-channel parameters, accumulator init: overlaps the loads above
 
-    for (int c = 0; c < g.nch; ++c) {
-        __syncthreads();   // every wave is done with the previous chunk's patch
-        if constexpr (STATS) {
-            const __bf16* src;
-            int cs, cbase;
-            if (c < g.nch0) { src = g.src0; cs = g.c0; cbase = c * BKC; }
-            else            { src = g.src1; cs = g.c1; cbase = (c - g.nch0) * BKC; }
+    int c = 0, t = 0;   // chunk and tap of the current step
+    auto step = [&](int s, bf16x8 (&cur)[WP], bf16x8 (&nxt)[WP]) {
+        if (t == 0) {
+            __syncthreads();   // every wave is done with the previous chunk's patch
+            if constexpr (STATS) {
+                const __bf16* src;
+                int cs, cbase;
+                if (c < g.nch0) { src = g.src0; cs = g.c0; cbase = c * BKC; }
+                else            { src = g.src1; cs = g.c1; cbase = (c - g.nch0) * BKC; }
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                const int idx = tid + k * NT;
-                if (idx < total) {
-                    const int r = idx / PPR, pc = idx % PPR;
-                    const int ix = ix0 + r, ch = cbase + pc * 8;
-                    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (ix < g.in_w && ch < cs)
-                        v = *reinterpret_cast<const bf16x8*>(src + ((long long)frame * g.in_h * g.in_w + ix) * cs + ch);
-                    *reinterpret_cast<bf16x8*>(patch + r * PROW + pc * 8) = v;
+                for (int k = 0; k < KMAX; ++k) {
+                    const int idx = tid + k * NT;
+                    if (idx < total) {
+                        const int r = idx / PPR, pc = idx % PPR;
+                        const int ix = ix0 + r, ch = cbase + pc * 8;
+                        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (ix < g.in_w && ch < cs)
+                            v = *reinterpret_cast<const bf16x8*>(src + ((long long)frame * g.in_h * g.in_w + ix) * cs + ch);
+                        *reinterpret_cast<bf16x8*>(patch + r * PROW + pc * 8) = v;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1[k] += f; s2[k] += f * f; }
+                        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1[k] += f; s2[k] += f * f; }
+                    }
                 }
+            } else {
+                patch_commit();
+                if (c + 1 < g.nch) patch_prefetch(c + 1);
             }
-        } else {
-            patch_commit();
-            if (c + 1 < g.nch) patch_prefetch(c + 1);
         }
-
-        for (int t = 0; t < ntp; ++t) {
-            const int s = c * ntp + t;
-            __bf16* wb = wbuf + (s & 1) * BN * BKC;
-            [[maybe_unused]] const unsigned long long ts0 = VDMI_STAMP_T();
+        __bf16* wb = wbuf + (s & 1) * BN * BKC;
+        [[maybe_unused]] const unsigned long long ts0 = VDMI_STAMP_T();
 #pragma unroll
-            for (int k = 0; k < WP; ++k) *reinterpret_cast<bf16x8*>(wb + (tid + k * NT) * 8) = wreg[k];
-            [[maybe_unused]] const unsigned long long ts1 = VDMI_STAMP_T();
+        for (int k = 0; k < WP; ++k) *reinterpret_cast<bf16x8*>(wb + (tid + k * NT) * 8) = cur[k];
+        [[maybe_unused]] const unsigned long long ts1 = VDMI_STAMP_T();
 #if !defined(VDMI_ABL) || VDMI_ABL != 4
-            __syncthreads();   // patch and this step's weight tile are visible
+        __syncthreads();   // patch and this step's weight tile are visible
 #else
-            if (s == 0) __syncthreads();
+        if (s == 0) __syncthreads();
 #endif
-            [[maybe_unused]] const unsigned long long ts2 = VDMI_STAMP_T();
-            VDMI_STAMP_ADD(diag, 5, ts1 - ts0);
-            VDMI_STAMP_ADD(diag, 6, ts2 - ts1);
-            if (s == 0) VDMI_STAMP(diag, 1);
+        [[maybe_unused]] const unsigned long long ts2 = VDMI_STAMP_T();
+        VDMI_STAMP_ADD(diag, 5, ts1 - ts0);
+        VDMI_STAMP_ADD(diag, 6, ts2 - ts1);
+        if (s == 0) VDMI_STAMP(diag, 1);
 #if !defined(VDMI_ABL) || VDMI_ABL != 3
-            if (s + 1 < nsteps) load_w(s + 1);
+        if (s + PD < nsteps) load_w(nxt, s + PD);
 #endif
-            const int to = g.toff[tap0 + t];
+        const int to = g.toff[tap0 + t];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 af[MI], bfr[NJ];
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 af[MI], bfr[NJ];
 #if !defined(VDMI_ABL) || VDMI_ABL != 2
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    af[i] = *reinterpret_cast<const bf16x8*>(wb + (((wn * MI + i) * KS + ks) * 64 + lane) * 8);
+            for (int i = 0; i < MI; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(wb + (((wn * MI + i) * KS + ks) * 64 + lane) * 8);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(patch + rowoff[j] + to + ks * 16);
+            for (int j = 0; j < NJ; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(patch + rowoff[j] + to + ks * 16);
 #else
 #pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = wreg[0];
+            for (int i = 0; i < MI; ++i) af[i] = cur[0];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) bfr[j] = wreg[0];
+            for (int j = 0; j < NJ; ++j) bfr[j] = cur[0];
 #endif
 #if !defined(VDMI_ABL) || VDMI_ABL != 1
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
 #else
 #pragma unroll
-                for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+            for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bfr[j]));
+            for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bfr[j]));
 #endif
-            }
-            VDMI_STAMP_ADD(diag, 7, VDMI_STAMP_T() - ts2);
         }
+        VDMI_STAMP_ADD(diag, 7, VDMI_STAMP_T() - ts2);
+        if (++t == ntp) { t = 0; ++c; }
+    };
+    // the ring of register sets has fixed names, so the step loop is unrolled by its depth
+    if constexpr (DEEP) {
+        for (int s = 0; s < nsteps; s += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u)
+                if (s + u < nsteps) step(s + u, wreg[u], wreg[(u + PD) % RING]);
+        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) step(s, wreg[0], wreg[0]);
     }
 
     if constexpr (STATS) {
@@ -339,6 +363,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
 __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4 : 2))) void tapgemm_kernel(const KArgs a) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32;
+    // deeper weight prefetch where it is free: plain epilogue, one 16-byte weight piece per thread and step
+    constexpr bool DEEP_MAIN = EPI == VDMI_EPI_PLAIN && BN * BKC / 8 == NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* wbuf = reinterpret_cast<__bf16*>(smem);
     float* par = reinterpret_cast<float*>(smem + 2 * BN * BKC * 2);
@@ -409,7 +435,7 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
 
     constexpr bool STATS = (EPI == VDMI_EPI_QKV_ATTN || EPI == VDMI_EPI_QKV_SLA);
     VDMI_STAMP(a.diag, 0);
-    run_pass<BM, BN, WM, WN, BKC, STATS>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag, phase);
+    run_pass<BM, BN, WM, WN, BKC, STATS, DEEP_MAIN>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag, phase);
     VDMI_STAMP(a.diag, 2);
     if constexpr (STATS) __syncthreads();   // row statistics written by the loader threads
 
@@ -466,7 +492,7 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
                     }
             }
         if (a.has_res == 1) {
-            run_pass<BM, BN, WM, WN, BKC, false>(a.res, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, 0.f, [] {});
+            run_pass<BM, BN, WM, WN, BKC, false, false>(a.res, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, 0.f, [] {});
             if (a.res_bias) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
