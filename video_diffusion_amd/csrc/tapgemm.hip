@@ -40,9 +40,13 @@
 #define VDMI_STAMP_ADD(ptr, slot, val) do { } while (0)
 #endif
 
-// steps ahead a weight tile is requested in the deep-prefetch kernels (register sets = this + 1)
+// steps ahead a weight tile is requested in the deep-prefetch kernels (register sets = this + 1; 1: one set,
+// refilled in place): plain epilogue / RMSNorm epilogue
 #ifndef VDMI_WPD
 #define VDMI_WPD 3
+#endif
+#ifndef VDMI_WPD_NORM
+#define VDMI_WPD_NORM 1
 #endif
 
 namespace {
@@ -108,7 +112,7 @@ constexpr int patch_lb(int bm, int nt) {
     return bm >= 256 ? (13 * 256 + nt - 1) / nt : (bm >= 64 ? (12 * 256 + nt - 1) / nt : 2);
 }
 
-template <int BM, int BN, int WM, int WN, int BKC, bool STATS, bool DEEP, class Pro>
+template <int BM, int BN, int WM, int WN, int BKC, bool STATS, int WPD, class Pro>
 __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32][WM / 32], __bf16* wbuf,
                                          __bf16* patch, float* stats, int frame, int ty, int tx, int ltw,
                                          int nt, int tid, float ln_eps, Pro&& after_first_loads,
@@ -140,10 +144,11 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     const int ntp = g.phases > 1 ? g.ntaps / g.phases : g.ntaps, tap0 = phase * ntp;   // this phase's taps
     wg += phase * g.w_phase_stride;
 
-    // weight tiles travel global -> registers -> LDS.  DEEP: three register sets, so the tile of step s + 2 is
-    // requested while step s computes (one step of MFMAs is shorter than an L2 round trip when few workgroups share
-    // a CU); otherwise one set, refilled for step s + 1 as soon as step s's tile is in LDS.
-    constexpr int PD = DEEP ? VDMI_WPD : 1, RING = DEEP ? PD + 1 : 1;
+    // weight tiles travel global -> registers -> LDS.  WPD > 1: WPD + 1 register sets, so the tile of step s + WPD
+    // is requested while step s computes (one step of MFMAs is shorter than an L2 round trip when few workgroups
+    // share a CU); WPD == 1: one set, refilled for step s + 1 as soon as step s's tile is in LDS.
+    constexpr bool DEEP = WPD > 1;
+    constexpr int PD = WPD, RING = DEEP ? PD + 1 : 1;
     bf16x8 wreg[RING][WP];
     auto load_w = [&](bf16x8 (&dst)[WP], int s) {
         const __bf16* p = wg + (long long)s * g.wtile_all;
@@ -363,8 +368,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
 __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4 : 2))) void tapgemm_kernel(const KArgs a) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32;
-    // deeper weight prefetch where it is free: plain epilogue, one 16-byte weight piece per thread and step
-    constexpr bool DEEP_MAIN = EPI == VDMI_EPI_PLAIN && BN * BKC / 8 == NT;
+    // deeper weight prefetch where the registers allow it: one 16-byte weight piece per thread and step
+    constexpr int WPD_MAIN = BN * BKC / 8 != NT ? 1 : EPI == VDMI_EPI_PLAIN ? VDMI_WPD : EPI == VDMI_EPI_NORM_SILU ? VDMI_WPD_NORM : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* wbuf = reinterpret_cast<__bf16*>(smem);
     float* par = reinterpret_cast<float*>(smem + 2 * BN * BKC * 2);
@@ -435,7 +440,7 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
 
     constexpr bool STATS = (EPI == VDMI_EPI_QKV_ATTN || EPI == VDMI_EPI_QKV_SLA);
     VDMI_STAMP(a.diag, 0);
-    run_pass<BM, BN, WM, WN, BKC, STATS, DEEP_MAIN>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag, phase);
+    run_pass<BM, BN, WM, WN, BKC, STATS, WPD_MAIN>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag, phase);
     VDMI_STAMP(a.diag, 2);
     if constexpr (STATS) __syncthreads();   // row statistics written by the loader threads
 
@@ -492,7 +497,7 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
                     }
             }
         if (a.has_res == 1) {
-            run_pass<BM, BN, WM, WN, BKC, false, false>(a.res, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, 0.f, [] {});
+            run_pass<BM, BN, WM, WN, BKC, false, 1>(a.res, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, 0.f, [] {});
             if (a.res_bias) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
