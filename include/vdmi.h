@@ -148,6 +148,11 @@ int vdmi_pack_taps(const float* w, int n, int npad, int cin0, int cin1, int ntap
 
 int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream);
 
+/* HOST. vdmi_tapgemm runs the 64 -> 64 channel (1,3,3) NORM_SILU convolutions of 32- and 64-pixel-wide images
+ * (Block.proj + RMSNorm + SiLU, vdp.py:412-427) on a weight-stationary kernel; 0 keeps every launch on the
+ * general tap-GEMM (tests and A/B timing; the environment variable VDMI_WSCONV=0 does the same for a process). */
+void vdmi_wsconv_enable(int on);
+
 /* ------------------------------------------------------------------------------------------
  * Cross-attention to previous-frame features: CrossAttention (vdp.py:480-528) inside
  * Residual(PreNorm(.)) at vdp.py:803-805 and :824-826, heads of 32 features.

@@ -836,6 +836,8 @@ extern "C" int vdmi_tapgemm_tile(int epilogue, int n, int* bn, int* bkc) {
     return VDMI_OK;
 }
 
+int vdmi_wsconv_try(const vdmi_tapgemm_args& A, hipStream_t stream);   // wsconv.hip
+
 extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) {
     if (!args || !args->out) return VDMI_E_ARG;
     const vdmi_tapgemm_args& A = *args;
@@ -855,6 +857,12 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if ((long long)A.frames * A.main.in_h * A.main.in_w > (A.main.space_to_depth ? 0x7ffffffLL : 0x7fffffffLL))
         return VDMI_E_SHAPE;
     if (A.main.space_to_depth && (epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA)) return VDMI_E_ARG;
+
+    // 64 -> 64 channel (1,3,3) convolutions of wide images: the weight-stationary kernel
+    if (epi == VDMI_EPI_NORM_SILU) {
+        const int ws = vdmi_wsconv_try(A, stream);
+        if (ws <= 0) return ws;
+    }
 
     TileCfg cands[4];
     int ncand = 0;
