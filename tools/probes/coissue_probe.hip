@@ -20,6 +20,8 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
         if (AMODE > 0) {
             f32x16 acc0 = {0}, acc1 = {0};
             bf16x8 w = *reinterpret_cast<const bf16x8*>(smem + lane * 16);
+            bf16x8 wa = w;
+            asm volatile("" : "+a"(wa));
             bf16x8 f[9];
             int addr = lane * 16 + wave * 8192;
 #pragma unroll
@@ -33,7 +35,13 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
                         f[(i + 8) % 9] = *reinterpret_cast<const bf16x8*>(smem + a2 + ((i * 1024) & 4095));
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, f[i % 9], acc1, 0, 0, 0);
+                    if (AMODE == 5) {      // inline asm, A operand in an accumulation register
+                        if (i & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "a"(wa), "v"(f[i % 9]));
+                        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "a"(wa), "v"(f[i % 9]));
+                    } else if (AMODE == 6) {   // inline asm, A operand in a vector register
+                        if (i & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(w), "v"(f[i % 9]));
+                        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(w), "v"(f[i % 9]));
+                    } else if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, f[i % 9], acc1, 0, 0, 0);
                     else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, f[i % 9], acc0, 0, 0, 0);
                     if (AMODE == 3) asm volatile("s_nop 3");
                     if (AMODE == 4) asm volatile("s_nop 15");
@@ -84,6 +92,8 @@ int main() {
     const int na = 1800, nb = 600;
     run<1, 0>("A: MFMA only, alone", out, cyc, na, nb);
     run<2, 0>("A: MFMA + ds_read + xor, alone", out, cyc, na, nb);
+    run<5, 0>("A: asm MFMA (A operand in AGPR) + ds_read, alone", out, cyc, na, nb);
+    run<6, 0>("A: asm MFMA (A operand in VGPR) + ds_read, alone", out, cyc, na, nb);
     run<0, 1>("B: fma body, alone", out, cyc, na, nb);
     run<0, 2>("B: silu body, alone", out, cyc, na, nb);
     run<1, 1>("A MFMA only | B fma", out, cyc, na, nb);

@@ -32,7 +32,7 @@ d = d[d[:, 0, 3] != 0].double()
 names = ["issue patch DMA", "epilogue: residual read, partner wait, rinv", "issue residual + init", "MFMA phase",
          "publish ss + wait DMA", "epilogue: math + staging writes", "barrier wait", "epilogue: stores"]
 print(f"{args.layer}: {d.shape[0]} workgroups")
-for role, sl in (("waves 0-3 (epilogue after MFMA)", slice(0, 4)), ("waves 4-7 (epilogue deferred)", slice(4, 8))):
+for role, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
     print(" ", role)
     for i, n in enumerate(names):
         x = d[:, sl, i]

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--parts", type=int, default=1)
+    ap.add_argument("--new", type=int, default=1, help="kernel generation to test (vdmi_wsconv_enable value)")
     args = ap.parse_args()
     from video_diffusion_amd import Unet3D, _lib
     from video_diffusion_amd import engine as E
@@ -71,7 +72,7 @@ def main():
         torch.cuda.synchronize()
         ref = out.float().clone()
         out.zero_()
-        lib.vdmi_wsconv_enable(1)
+        lib.vdmi_wsconv_enable(args.new)
         assert c.fn(s) == 0
         torch.cuda.synchronize()
         got = out.float()
@@ -92,14 +93,14 @@ def main():
         for _ in range(args.rounds):
             lib.vdmi_wsconv_enable(0)
             t_old.append(timeit())
-            lib.vdmi_wsconv_enable(1)
+            lib.vdmi_wsconv_enable(args.new)
             t_new.append(timeit())
         fl = (c.args or {}).get("flops", 0.0)
         same = abs(min(t_old) - min(t_new)) < 0.02 * min(t_old)
         print(f"{c.name:28s} rel {err:.2e} max {mx:.3f} bad {bad:6d}  old {min(t_old):7.1f} us ({fl / min(t_old) / 1e6:6.0f} TF)"
               f"  new {min(t_new):7.1f} us ({fl / min(t_new) / 1e6:6.0f} TF){'  [same kernel?]' if same else ''}")
         taken.append((min(t_old), min(t_new)))
-    lib.vdmi_wsconv_enable(1)
+    lib.vdmi_wsconv_enable(args.new)
     plan.run()
     torch.cuda.synchronize()
     e = float((plan.eps_out - eps_old).norm() / eps_old.norm())

@@ -11,42 +11,26 @@
 //   * tile = 256 pixels = a band of TH = 256 / W full image rows (W = 64 or 32).  The band plus its one-pixel halo
 //     is loaded straight into LDS by buffer_load ... lds (no register staging; pixels outside the image come
 //     back as zeros from the buffer bounds check) into one of two buffers: tile i+1 lands while tile i computes.
-//     LDS image of a buffer: [k-step 0..3][patch pixel][32 B] (the 16 input channels of a k-step), the two
-//     16-byte halves swapped on every other group of 8 pixels, so a wave's ds_read_b128 of 32 consecutive
-//     pixels is conflict-free and tap / k-step are immediate offsets.
+//     LDS image of a buffer: [patch pixel][128 B], the eight 16-byte chunks of a pixel stored at slot
+//     chunk ^ ((pixel >> 1) & 7): every 1-KiB DMA piece is 8 whole rows of the source tensor (fully coalesced) and a
+//     wave's ds_read_b128 of one chunk of 32 consecutive pixels is conflict-free.
+//   * matrix phase of a tile: 72 steps of {request the pixel fragment needed 8 steps later, MFMA}, pinned in that
+//     order (the scheduler, left alone, requests each fragment right before its use and the wave then waits out
+//     the LDS latency 72 times per tile).
 //   * one workgroup barrier per tile.  RMSNorm needs the sum of squares over all 64 channels: the two waves
 //     that share a pixel group exchange their halves through LDS with a sequence flag (no barrier).
-//   * waves 4-7 run the epilogue of tile i-1 BEFORE the MFMAs of tile i, waves 0-3 run the epilogue of tile i
-//     after its MFMAs: waves w and w+4 share a SIMD, so on every SIMD one wave is in its matrix phase while
-//     the other does the epilogue's vector work (exp, rcp, conversions, stores).
 //   * output: each wave transposes its 64 x 32 result through a private 4-KiB LDS region (the identity
 //     residual is DMA'd into the same region beforehand) and stores 16 B per lane, 64 B per pixel.
+//
+// Measured on the device while building this (tools/probes/coissue_probe.hip, mix_probe.hip): a wave that issues
+// MFMAs back to back leaves the other wave of its SIMD about one vector instruction per MFMA (a VALU-bound partner
+// ran ~13x slower), so the epilogue of one wave does NOT hide behind the matrix phase of its SIMD partner: letting
+// waves w and w+4 run half a tile apart bought nothing, and every wave here simply runs matrix phase, then epilogue.
+// Vector work hides only inside the issuing wave's own MFMA gaps (about 6 instructions per gap at one wave per
+// SIMD); a variant built that way (4 waves of 512 registers, epilogue of the previous tile woven into the MFMA
+// stream) was correct but issue-bound at ~60 cycles per MFMA and slower than this kernel.
 #include "vdmi_common.h"
 #include <cstdlib>
-
-// build-time experiment switches (defaults = the shipped configuration)
-#ifndef WS_PRIO
-#define WS_PRIO 1          // 0: no priorities, 1: matrix phase at priority 1, 2: epilogue at priority 1
-#endif
-#ifndef WS_DMA_WAVES
-#define WS_DMA_WAVES 8     // waves that issue the patch DMA: 8 = all, 4 = waves 0-3 only
-#endif
-#ifndef WS_DIST
-#define WS_DIST 8          // pixel fragments requested ahead of the MFMA that uses them
-#endif
-
-#ifndef WS_PAD
-#define WS_PAD 0           // idle cycles (s_nop) after every MFMA of the matrix phase: leaves the issue port to the partner wave
-#endif
-#ifndef WS_SWAP
-#define WS_SWAP 0          // 1: waves 0-3 defer their epilogue instead of waves 4-7
-#endif
-#ifndef WS_NOSTAGGER
-#define WS_NOSTAGGER 0     // 1: every wave runs its epilogue right after its matrix phase
-#endif
-#ifndef WS_YOUNG_PRIO
-#define WS_YOUNG_PRIO 0    // 1: waves 4-7 run at priority 1 throughout
-#endif
 
 namespace {
 
@@ -101,7 +85,7 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = WS_NOSTAGGER ? 0 : (wave >> 2) ^ WS_SWAP, s = wave & 1, g = ((wave >> 1) & 1) + 2 * (wave >> 2);
+    const int s = wave & 1, g = wave >> 1;         // output-channel slice, pixel group
 
     // ---- this wave's weights: 32 output channels x (9 taps x 64 inputs), resident in registers
     bf16x8 wr[9][4];
@@ -133,7 +117,7 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
     // j % 8.  What a lane fetches for piece j never changes relative to the tile's first haloed pixel, so it is kept:
     // prel = byte offset | flags (bit 0: pixel of the top halo row, bit 1: of the bottom halo row, bit 2: never
     // inside the image -- left / right halo column or padding of the last piece).
-    constexpr int DW = WS_DMA_WAVES, NJ = (NINSTR + DW - 1) / DW;
+    constexpr int DW = 8, NJ = (NINSTR + DW - 1) / DW;
     int prel[NJ];
 #pragma unroll
     for (int u = 0; u < NJ; ++u) {
@@ -151,7 +135,7 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
 #pragma unroll
         for (int u = 0; u < NJ; ++u) {
             const int j = wave + DW * u;
-            if (wave < DW && j < NINSTR) {
+            if (j < NINSTR) {
                 const unsigned off = (prel[u] & m) ? 0x80000000u : (unsigned)((prel[u] & ~15) + base);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(smem + buf * PBUF + j * 1024), 16, off, 0, 0, 0);
             }
@@ -212,7 +196,7 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
     // i + DIST is requested before the MFMA of step i, in exactly this order (the scheduler left to itself requests
     // each fragment right before its use and the wave then waits out the LDS latency 72 times per tile).
     auto mfma_phase = [&](int buf) {
-        constexpr int DIST = WS_DIST, NBUF = DIST + 1;
+        constexpr int DIST = 8, NBUF = DIST + 1;
         const char* pb = smem + buf * PBUF;
         // keep the per-tap addresses inside the loop (hoisted, they cost ~40 registers)
         asm volatile("" : "+v"(pq[0]), "+v"(pq[1]));
@@ -228,17 +212,13 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
         };
 #pragma unroll
         for (int i = 0; i < DIST; ++i) request(i);
-        if (WS_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 72; ++i) {
             if (i + DIST < 72) request(i + DIST);
             __builtin_amdgcn_sched_barrier(0);
             acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[i >> 3][(i & 7) >> 1], fr[i % NBUF], acc[i & 1], 0, 0, 0);
-            if (WS_PAD > 0) asm volatile("s_nop %0" ::"n"(WS_PAD > 16 ? 15 : (WS_PAD > 0 ? WS_PAD - 1 : 0)));
-            if (WS_PAD > 16) asm volatile("s_nop %0" ::"n"(WS_PAD > 16 ? WS_PAD - 17 : 0));
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (WS_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
 
     // sum of squares over this wave's 32 channels, published for the wave that holds the other 32
@@ -258,7 +238,6 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
     };
 
     auto epilogue = [&](int t, int seq) {
-        if (WS_PRIO == 2) __builtin_amdgcn_s_setprio(1);
         char* stg = smem + OFF_STG + wave * 4096;
         // staging address of this lane's 4 channels 8*rg + 4*h .. of pixel row nb*32 + l31: row*64 + ((rg ^ swz) << 4) + 8*h
         const int srow[2] = {l31 * 64 + 8 * h, (32 + l31) * 64 + 8 * h};
@@ -306,11 +285,9 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_out, out_voff,
                                                        (unsigned)((prow0 + it * 16) * a.ldo * 2), 0);
         }
-        if (WS_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         WS_ACC(7, ts);
     };
 
-    if (WS_YOUNG_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int stride = gridDim.x;
     int tile = blockIdx.x;
     __syncthreads();                       // bias / parameter / flag initialisation
@@ -323,7 +300,6 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
     for (; tile < a.ntiles; tile += stride, ++k) {
         if (tile + stride < a.ntiles) issue_patch(tile + stride, (k + 1) & 1, (k + 1) % 3);
         WS_ACC(0, ts);
-        if (role == 1 && k > 0) epilogue(tile - stride, k - 1);
         if constexpr (RES) issue_res(tile);
         init_acc();
         WS_ACC(2, ts);
@@ -333,16 +309,16 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
         WS_ACC(4, ts);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // patch of the next tile, residual of this one
         WS_ACC(4, ts);
-        if (role == 0) epilogue(tile, k);
+        epilogue(tile, k);
         __builtin_amdgcn_s_barrier();
         WS_ACC(6, ts);
     }
-    if (role == 1 && k > 0) epilogue(tile - stride, k - 1);
 #ifdef VDMI_DIAG_STAMPS
     if (a.diag && lane == 0)
         for (int i = 0; i < 8; ++i) a.diag[((size_t)blockIdx.x * 8 + wave) * 8 + i] = dsum[i];
 #endif
 }
+
 
 int g_ws_enabled = -1;
 
