@@ -4,12 +4,18 @@
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+    python -m torch.distributed.run ... bench.py --gpus N --global-batch 256       # BASELINE configs[2]
+
 One "step" = one denoise step (Unet3D forward + posterior update) over the local batch, replayed
 as one captured HIP graph.  Workload at every N: BASELINE.json configs[1] per GPU — Unet3D(dim=64,
 dim_mults=(1,2,4,8), channels=1), x = (16, 1, 10, 64, 64), bf16 kernels / fp32 sampler state,
 GaussianDiffusion(timesteps=1000), random-init weights, synthetic noise input.  The batch is
 sharded by sample (weak scaling: 16 videos per GPU); the only collective is the all-gather of the
-finished videos, timed separately.
+finished videos, timed separately.  With --global-batch G the same model samples G videos in total,
+G / N per GPU (strong scaling at a fixed global batch: BASELINE.json configs[2] for G = 256).
+
+After the timed steps every rank runs one real p_sample_loop of all 1000 steps; its wall time is
+reported beside the extrapolated figure (full_loop_s, videos_per_s_measured).
 """
 import argparse
 import json
@@ -29,11 +35,29 @@ CFG1 = dict(dim=64, dim_mults=(1, 2, 4, 8), channels=1)
 FRAMES, SIZE, TIMESTEPS = 10, 64, 1000
 
 
+def physical_cores():
+    """Physical cores of the host (sockets x cores per socket, from lscpu); None when lscpu is not there."""
+    import subprocess
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = dict((k.strip(), v.strip()) for k, v in (ln.split(":", 1) for ln in txt.splitlines() if ":" in ln))
+        return int(kv["Socket(s)"]) * int(kv["Core(s) per socket"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(batch, steps):
-    """The CPU oracle (fp32 restatement of the reference path) on the host cores, bounded sample."""
+    """The CPU oracle (fp32 restatement of the reference path) on the host cores, bounded sample.
+
+    Threads: one per physical core of the host, but no more than the share of the machine this process is given
+    (the affinity mask, and OMP_NUM_THREADS when the launcher sets it): more threads than that only contend."""
     from oracle import vdm_oracle as O
     from video_diffusion_amd import Unet3D
-    threads = min(16, os.cpu_count() or 1)
+    phys = physical_cores()
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        share = min(share, int(os.environ["OMP_NUM_THREADS"]))
+    threads = max(1, min(phys or share, share))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     m = Unet3D(**CFG1)
@@ -54,8 +78,9 @@ def cpu_baseline(batch, steps):
         dt = time.perf_counter() - t0
     steps_per_s = steps / dt
     return {"value": batch * steps_per_s / TIMESTEPS, "unit": "videos/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} denoise steps at batch {batch} of the same model/shape, fp32, torch CPU "
-                      f"({dt:.1f} s); videos/s = batch*steps/s/{TIMESTEPS}",
+            "physical_cores_of_host": phys, "cpu_share_of_process": share,
+            "sample": f"{steps} denoise steps at batch {batch} of the same model/shape, fp32, torch CPU on {threads} "
+                      f"threads ({dt:.1f} s); videos/s = batch*steps/s/{TIMESTEPS}",
             "denoise_steps_per_s": steps_per_s}
 
 
@@ -65,6 +90,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="videos per GPU")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total videos over all GPUs (strong scaling; 256 = BASELINE configs[2]); overrides --batch")
+    ap.add_argument("--no-full-loop", action="store_true", help="skip the real 1000-step loop after the timed steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parts", type=int, default=None,
                     help="concurrent sub-batches one forward is run as (default: the library's choice)")
@@ -92,6 +120,11 @@ def main():
     from video_diffusion_amd import GaussianDiffusion, Unet3D
     from video_diffusion_amd.parallel import gather_videos
 
+    if args.global_batch is not None:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
+        args.batch = args.global_batch // world
+
     from video_diffusion_amd import engine as vd_engine
     if args.parts is not None:
         vd_engine.BATCH_PARTS = args.parts
@@ -108,11 +141,12 @@ def main():
 
     graph, plan = gd._graph_runner(shape, device)
     plan.x_in.copy_(torch.randn(shape, device=device))
-    seed = 99 + rank
+    gd.reseed_noise(device)                       # Philox key in device memory (ranks are seeded differently above)
+    rng = gd._rng_state(device)
 
     def eager_step():
         plan.run()
-        gd.ddpm_step(plan.x_in, plan.eps_out, plan.t_in, noise=None, clip_denoised=True, out=plan.x_in, seed=seed)
+        gd.ddpm_step(plan.x_in, plan.eps_out, plan.t_in, noise=None, clip_denoised=True, out=plan.x_in, rng_state=rng)
 
     def step(i):
         plan.t_in.fill_(TIMESTEPS - 1 - (i % TIMESTEPS))
@@ -141,6 +175,24 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(plan.x_in).all(), "sampler state went non-finite"
+
+    # ---- one real loop: x_T drawn, all 1000 steps, fresh Philox key (the product entry point, nothing extrapolated) ----
+    full_loop_s = None
+    if not args.no_full_loop:
+        gd.use_hip_graph = not args.no_graph
+        barrier()
+        torch.cuda.synchronize()
+        f0 = time.perf_counter()
+        videos = gd.p_sample_loop(shape)
+        torch.cuda.synchronize()
+        barrier()
+        full_loop_s = time.perf_counter() - f0
+        if world > 1:
+            tt = torch.tensor([full_loop_s], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            full_loop_s = float(tt.item())
+        assert videos.shape == shape and torch.isfinite(videos).all()
+        del videos
 
     # the one collective of the sharded sampler: all-gather of the finished videos
     gather_ms = None
@@ -193,15 +245,19 @@ def main():
         dom = classes[dom_key]
         avg_ms = dom["ms_per_step"] / dom["launches_per_step"]
         achieved = dom["flops_per_step"] / (dom["ms_per_step"] * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom_key)
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom_key)
+                traffic_source = ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, "
+                                  "not collected in this run): " + str(tj.get("_source", "source not recorded")))
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma", "kernel": dom_key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": dom["launches_per_step"],
                     "videos_per_launch": B // parts,
                     "algorithmic_gflop_per_launch": round(dom["flops_per_step"] / dom["launches_per_step"] / 1e9, 2)}
@@ -230,6 +286,30 @@ def main():
                                               "avg_launch_ms": round(wc["ms_per_step"] / wc["launches_per_step"], 4),
                                               "launches_per_step": wc["launches_per_step"]}
             del whole
+        # the HBM-bound classes on their own roofline: algorithmic bytes over the launch time, against 8 TB/s
+        hbm = {}
+        if "rmsnorm_silu" in classes:
+            c = classes["rmsnorm_silu"]
+            gbs = c["bytes_per_step"] / (c["ms_per_step"] * 1e-3) / 1e9
+            hbm["rmsnorm_silu"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": c["launches_per_step"],
+                                   "avg_launch_ms": round(c["ms_per_step"] / c["launches_per_step"], 4)}
+        reps = 20
+        scratch_x = plan.x_in.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gd.ddpm_step(scratch_x, plan.eps_out, plan.t_in, noise=None, out=scratch_x, rng_state=rng)
+        e0.record()
+        for _ in range(reps):
+            gd.ddpm_step(scratch_x, plan.eps_out, plan.t_in, noise=None, out=scratch_x, rng_state=rng)
+        e1.record()
+        torch.cuda.synchronize()
+        d_ms = e0.elapsed_time(e1) / reps
+        d_bytes = scratch_x.numel() * (2 * scratch_x.element_size() + plan.eps_out.element_size())
+        hbm["ddpm_step"] = {"achieved": round(d_bytes / (d_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(d_bytes / (d_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches_per_step": 1,
+                            "avg_launch_ms": round(d_ms, 4),
+                            "algorithmic_bytes_per_launch": d_bytes}
+        roofline["hbm_classes"] = hbm
         breakdown = {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches": v["launches_per_step"],
                          "tflops": round(v["flops_per_step"] / (v["ms_per_step"] * 1e-3) / 1e12, 1) if v["flops_per_step"] else None,
                          "alg_gbs": round(v["bytes_per_step"] / (v["ms_per_step"] * 1e-3) / 1e9, 1) if v["bytes_per_step"] else None}
@@ -242,10 +322,14 @@ def main():
             "metric": "sampled videos/sec + denoise steps/sec, 10x64x64 MovingMNIST, 1/2/4/8 MI355X",
             "value": round(videos_per_s, 4), "unit": "videos/s (T=1000 DDPM steps per video)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if args.global_batch is not None else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Unet3D(dim=64,dim_mults=(1,2,4,8),channels=1), "
-                                   "p_sample over x=(16,1,10,64,64) per GPU, T=1000, random-init weights",
+            "config": {"workload": (f"BASELINE configs[2]: Unet3D(dim=64,dim_mults=(1,2,4,8),channels=1), global batch "
+                                    f"{args.global_batch} sharded over {world} GPU(s) = x=({B},1,10,64,64) per GPU, "
+                                    "T=1000, random-init weights") if args.global_batch is not None else
+                                   ("BASELINE configs[1]: Unet3D(dim=64,dim_mults=(1,2,4,8),channels=1), "
+                                    f"p_sample over x=({B},1,10,64,64) per GPU, T=1000, random-init weights"),
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": TIMESTEPS,
                        "launch": "eager" if args.no_graph else "hip-graph replay",
                        "concurrency": f"{parts} sub-batch(es) of {B // parts} videos on {parts} HIP stream(s)",
@@ -254,10 +338,12 @@ def main():
             "sample_steps_per_s": round(B * world * steps_per_s, 2),
             "model_tflops": round(154.5e9 * B * world * steps_per_s / 1e12, 1),
             "allgather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "full_loop_s": None if full_loop_s is None else round(full_loop_s, 3),
+            "videos_per_s_measured": None if full_loop_s is None else round(B * world / full_loop_s, 4),
             "roofline": roofline, "breakdown_ms_per_step": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch=4, steps=10)
+            out["cpu_baseline"] = cpu_baseline(batch=16, steps=3)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -152,6 +152,9 @@ int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream);
  * (Block.proj + RMSNorm + SiLU, vdp.py:412-427) on a weight-stationary kernel; 0 keeps every launch on the
  * general tap-GEMM (tests and A/B timing; the environment variable VDMI_WSCONV=0 does the same for a process). */
 void vdmi_wsconv_enable(int on);
+/* 1 when vdmi_tapgemm would run this launch on the weight-stationary kernel, else 0 (for profiles and tools that
+ * label launches by the kernel that runs them). */
+int vdmi_wsconv_covers(const vdmi_tapgemm_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * Cross-attention to previous-frame features: CrossAttention (vdp.py:480-528) inside
@@ -320,6 +323,13 @@ typedef struct vdmi_ddpm_coefs {
 int vdmi_ddpm_step(const float* x, const float* eps, const float* z, const int64_t* t,
                    const vdmi_ddpm_coefs* coefs, float* out, int b, int64_t per_sample, int clip,
                    uint64_t seed, uint64_t offset, vdmi_stream stream);
+
+/* The same step with in-kernel noise (the randn_like of vdp.py:1000) whose Philox key and counter offset are read
+ * from device memory: rng_state = uint64 [2] = {seed, offset}, 8-byte aligned.  A sampling loop captured in a HIP graph
+ * gets fresh noise on every call by rewriting these two words before it replays; the counter of element group g of
+ * sample i at timestep t is (t * b + i) * groups_per_sample + g + offset, so within one loop no counter repeats. */
+int vdmi_ddpm_step_rng(const float* x, const float* eps, const int64_t* t, const vdmi_ddpm_coefs* coefs,
+                       float* out, int b, int64_t per_sample, int clip, const uint64_t* rng_state, vdmi_stream stream);
 
 #ifdef __cplusplus
 }

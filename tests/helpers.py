@@ -40,3 +40,13 @@ def rel_err(a, b):
 
 
 inp = weightgen.synthetic_input
+
+
+# measured parity errors of the run, written by tests/conftest.py at session end (profiles/parity_errors.json is a copy)
+PARITY_LOG = {}
+
+
+def record(name, err, bar=None):
+    """Remember a measured error (and the bar it was held to) under `name`; returns err."""
+    PARITY_LOG[name] = {"rel_err": float(err), "bar": bar}
+    return err

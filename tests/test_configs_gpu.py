@@ -1,0 +1,210 @@
+"""GPU parity at the shapes of BASELINE.json's configs that the layer tests do not reach, and of the sampling loop as
+the benchmark runs it (HIP-graph replay, in-kernel Philox noise).
+
+Reference arithmetic: video_diffusion_pytorch/video_diffusion_pytorch.py:731-754 (classifier-free guidance branches),
+:756-831 (Unet3D.forward), :973-1014 (p_sample / p_sample_loop) of the reference.  Tolerance: BASELINE.json's bf16 bar,
+2e-2 relative L2 error per epsilon prediction; the full-loop bound is stated at its test.
+"""
+import pytest
+import torch
+
+from tests.helpers import CFG0, CFG1, CFG3, TINY, golden, inp, make_unet, record, rel_err
+
+pytestmark = pytest.mark.gpu
+
+MODEL_TOL = 2e-2
+CFG4 = dict(dim=128, dim_mults=(1, 2, 4, 8), channels=3)
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B", [32, 64, 128])
+def test_shard_sizes_of_global_batch_256(B):
+    """configs[2]: global batch 256 over 8 / 4 / 2 GPUs = shards of 32 / 64 / 128 videos.  Samples never interact, so
+    the epsilon of a shard equals the epsilon of its 16-video slices bit for bit (the 16-video batch is the one
+    pinned to the reference), and the reference's B = 2 golden embedded in the shard holds at 2e-2."""
+    m = make_unet(**CFG1).to(dev())
+    g = golden("cfg1_eps")
+    x = inp(f"cfg1.shard{B}", (B, 1, 10, 64, 64)).to(dev())
+    t = (torch.arange(B, device=dev()) * 37) % 1000
+    x[5:7] = inp("cfg1.x", (2, 1, 10, 64, 64)).to(dev())
+    t[5:7] = g["t"].to(dev())
+    with torch.no_grad():
+        full = m(x, t)
+        for s in range(0, B, 16):
+            part = m(x[s:s + 16], t[s:s + 16])
+            assert torch.equal(full[s:s + 16], part), (B, s)
+    assert record(f"cfg1_eps_inside_shard_of_{B}", rel_err(full[5:7].cpu(), g["eps"]), MODEL_TOL) < MODEL_TOL
+
+
+def test_cfg3_guidance_branches_vs_reference():
+    """configs[3]: the conditional and the null-conditioned evaluation of forward_with_cond_scale, each on its own."""
+    m = make_unet(**CFG3).to(dev())
+    g = golden("cfg3_branches")
+    x, c = inp("cfg3.x", (1, 3, 16, 64, 64)).to(dev()), inp("cfg3.cond", (1, 768)).to(dev())
+    with torch.no_grad():
+        e_c = m(x, g["t"].to(dev()), cond=c, null_cond_prob=0.)
+        e_n = m(x, g["t"].to(dev()), cond=c, null_cond_prob=1.)
+    assert record("cfg3_eps_cond", rel_err(e_c.cpu(), g["eps_cond"]), MODEL_TOL) < MODEL_TOL
+    assert record("cfg3_eps_null", rel_err(e_n.cpu(), g["eps_null"]), MODEL_TOL) < MODEL_TOL
+
+
+def test_cfg4_shape_eps_vs_reference():
+    """configs[4] shape on the forward path: Unet3D(dim=128, channels=3) on one 16 x 128 x 128 RGB clip."""
+    m = make_unet(**CFG4).to(dev())
+    g = golden("cfg4_eps")
+    x = inp("cfg4.x", (1, 3, 16, 128, 128)).to(dev())
+    with torch.no_grad():
+        eps = m(x, g["t"].to(dev()))
+    assert record("cfg4_eps", rel_err(eps.cpu(), g["eps"].float()), MODEL_TOL) < MODEL_TOL
+
+
+def test_cfg0_full_loop_T250_vs_reference():
+    """configs[0], the whole free-running loop: 250 steps from the reference's x_T with the reference's noise
+    draws, every step feeding the next (no teacher forcing).
+
+    What the fixtures say about this loop (random closed-form weights, x_0 clipped to [-1, 1] every step):
+      * the fp32 reference with nothing but its epsilon rounded to bf16 ends 7e-4 from itself: the loop is stable;
+      * a bf16 implementation's per-step error is mostly a FIXED perturbation (rounded weights, the same rounding
+        pattern on nearly the same activations step after step), so it adds up coherently over the 250 steps;
+      * the reference itself under torch.autocast(bfloat16) is the yardstick: its states and final sample are in
+        cfg0_full_T250_autocast, and the HIP loop may not drift further from the fp32 reference than 1.25 x that.
+    Every measured number goes to the parity log."""
+    from video_diffusion_amd import GaussianDiffusion
+    m = make_unet(**CFG0).to(dev())
+    g, ga = golden("cfg0_full_T250"), golden("cfg0_full_T250_autocast")
+    shape = (1, 3, 5, 32, 32)
+    gd = GaussianDiffusion(m, torch.nn.Identity(), image_size=32, num_frames=5, channels=3, timesteps=250).to(dev())
+    noises = [inp(f"cfg0.full.z{k}", shape) for k in range(250)]
+    x_T = inp("cfg0.full.xT", shape)
+    out = gd.p_sample_loop(shape, x_T=x_T, noises=noises)
+    assert torch.isfinite(out).all()
+    # the same loop step by step, to read the state at the steps the fixture holds
+    marks = [int(k) for k in g["marks"]]
+    x = x_T.to(dev())
+    for k, i in enumerate(reversed(range(250))):
+        if k in marks:
+            j = marks.index(k)
+            e_hip = rel_err(x.cpu(), g["states"][j].float())
+            e_auto = rel_err(ga["states"][j].float(), g["states"][j].float())
+            record(f"cfg0_full_loop_state_after_{k}_steps", e_hip, None)
+            record(f"cfg0_full_loop_state_after_{k}_steps_reference_autocast_bf16", e_auto, None)
+        x = gd.p_sample(x, torch.full((1,), i, device=dev(), dtype=torch.long), noise=noises[k].to(dev()))
+    assert torch.equal(x, out)                                   # the loop entry point is these 250 steps
+    e_auto = record("cfg0_full_loop_T250_final_sample_reference_autocast_bf16", rel_err(ga["final"], g["final"]), None)
+    e_round = record("cfg0_full_loop_T250_final_sample_reference_eps_rounded_to_bf16",
+                     rel_err(g["final_bf16eps"], g["final"]), None)
+    bar = 1.25 * e_auto
+    assert e_round < 2e-3
+    assert record("cfg0_full_loop_T250_final_sample", rel_err(out.cpu(), g["final"]), bar) < bar
+
+
+def _tiny_gd(T=8):
+    from video_diffusion_amd import GaussianDiffusion
+    m = make_unet(**TINY).to(dev())
+    gd = GaussianDiffusion(m, torch.nn.Identity(), image_size=12, num_frames=4, channels=3, timesteps=T).to(dev())
+    gd.noise_source = "philox"
+    return gd
+
+
+def test_graph_replay_equals_eager_loop_with_philox():
+    """The benchmarked path (HIP-graph replay, timestep tables, sub-batch streams, in-kernel Philox) gives the same
+    samples, bit for bit, as the eager loop of separate launches keyed with the same seed."""
+    gd = _tiny_gd()
+    shape = (6, 3, 4, 12, 12)
+    x_T = inp("graph.xT", shape)
+    torch.manual_seed(77)
+    gd.use_hip_graph = True
+    a = gd.p_sample_loop(shape, x_T=x_T)
+    assert gd._graphs, "the loop did not go through a captured graph"
+    torch.manual_seed(77)
+    gd.use_hip_graph = False
+    b = gd.p_sample_loop(shape, x_T=x_T)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_philox_noise_differs_between_calls():
+    """Two loops of the same shape on one object (the second replays the cached graph) draw different noise; the same
+    torch seed reproduces a loop."""
+    gd = _tiny_gd()
+    shape = (2, 3, 4, 12, 12)
+    x_T = inp("philox.xT", shape)
+    torch.manual_seed(5)
+    a = gd.p_sample_loop(shape, x_T=x_T)
+    b = gd.p_sample_loop(shape, x_T=x_T)
+    torch.manual_seed(5)
+    c = gd.p_sample_loop(shape, x_T=x_T)
+    assert not torch.equal(a, b)
+    assert float((a - b).abs().mean()) > 1e-2          # a different noise field, not a rounding difference
+    assert torch.equal(a, c)
+
+
+def test_weights_rewritten_through_data_are_repacked():
+    """In-place writes through `.data` (the reference's EMA, `p.data.copy_`) change neither the pointer nor autograd's
+    version counter.  The sampling loop notices them through its per-loop value fingerprint, a bare forward after
+    Unet3D.weights_changed()."""
+    gd = _tiny_gd()
+    m = gd.denoise_fn
+    shape = (2, 3, 4, 12, 12)
+    x_T = inp("stale.xT", shape)
+    torch.manual_seed(3)
+    a = gd.p_sample_loop(shape, x_T=x_T)
+    x, t = inp("stale.x", shape).to(dev()), torch.tensor([3, 5], device=dev())
+    saved = [p.detach().clone() for p in m.parameters()]
+    with torch.no_grad():
+        e0 = m(x, t)
+        for p in m.parameters():
+            p.data.mul_(1.25)
+    torch.manual_seed(3)
+    b = gd.p_sample_loop(shape, x_T=x_T)                       # same seed, same x_T: only the weights differ
+    assert not torch.equal(a, b)
+    with torch.no_grad():
+        for p, q in zip(m.parameters(), saved):
+            p.data.copy_(q)
+        e_stale = m(x, t)                                       # a bare forward does not look at values ...
+        m.weights_changed()
+        e1 = m(x, t)                                            # ... until it is told
+    assert not torch.equal(e_stale, e0) and torch.equal(e1, e0)
+    torch.manual_seed(3)
+    c = gd.p_sample_loop(shape, x_T=x_T)
+    assert torch.equal(c, a)
+
+
+def test_sla_pass1_beside_fold_kernels_on_another_stream():
+    """The fused linear attention's pass 1 on one stream while the fold / context kernels of another plan run on a
+    second stream: its workspace (partial sums, folded weights) must equal the serial run bit for bit.  (An earlier
+    version of the fold kernels, with three MFMAs chained into one accumulator, made this fail.)"""
+    from video_diffusion_amd.engine import Plan
+    m = make_unet(**CFG1).to(dev())
+    eng = m.engine()
+    eng.ensure_packed(dev())
+    p0, p1 = Plan(eng, 4, 10, 64, 64, dev()), Plan(eng, 4, 10, 64, 64, dev())
+    main = torch.cuda.current_stream()
+    for p in (p0, p1):
+        p.x_in.copy_(inp("conc.x", tuple(p.x_in.shape)).to(dev()))
+        p.t_in.fill_(500)
+        for c in p.calls:
+            assert c.fn(main.cuda_stream) == 0
+    torch.cuda.synchronize()
+    name = "ups.3.2.fused"
+    i0 = [i for i, c in enumerate(p0.calls) if c.name == name][0]
+    ws = [k for k in p0.keep if isinstance(k, torch.Tensor) and k.dtype == torch.uint8]
+    p0.calls[i0].fn(main.cuda_stream)
+    torch.cuda.synchronize()
+    ref = [w.clone() for w in ws]
+    others = [c for c in p1.calls if c.name.endswith(".fused") or c.name.endswith(".ctx")]
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(10):
+        s0.wait_stream(main)
+        s1.wait_stream(main)
+        for k, c in enumerate(others * 2):
+            c.fn(s1.cuda_stream)
+            if k == 0:
+                p0.calls[i0].fn(s0.cuda_stream)
+        main.wait_stream(s0)
+        main.wait_stream(s1)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ws, ref)), it

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import vdm_oracle as O
-from tests.helpers import (CFG0, CFG1, CFG3, TINY, TINY_COND, golden, inp, make_unet, oracle_cfg, rel_err)
+from tests.helpers import (CFG0, CFG1, CFG3, TINY, TINY_COND, golden, inp, make_unet, oracle_cfg, record, rel_err)
 
 pytestmark = pytest.mark.gpu
 
@@ -715,7 +715,7 @@ def test_tiny_eps_vs_reference(tiny):
     x = inp("tiny.x", (B, 3, Fr, H, H))
     with torch.no_grad():
         eps = m.to(dev())(x.to(dev()), g["t"].to(dev()))
-    assert rel_err(eps.cpu(), g["eps"]) < MODEL_TOL
+    assert record("tiny_eps", rel_err(eps.cpu(), g["eps"]), MODEL_TOL) < MODEL_TOL
 
 
 def test_tiny_cond_cfg_vs_reference():
@@ -791,7 +791,7 @@ def test_cfg0_six_steps_free_running_vs_reference():
     img = inp("cfg0.xT", shape).to(dev())
     for k, i in enumerate(reversed(range(244, 250))):
         img = gd.p_sample(img, torch.full((1,), i, device=dev(), dtype=torch.long), noise=inp(f"cfg0.z{k}", shape).to(dev()))
-    assert rel_err(img.cpu(), g["out"]) < 3e-2
+    assert record("cfg0_six_steps_free_running", rel_err(img.cpu(), g["out"]), 3e-2) < 3e-2
 
 
 def test_graph_loop_runs(tiny):
@@ -815,7 +815,7 @@ def test_cfg0_eps_vs_reference():
     with torch.no_grad():
         for tt in (0, 125, 249):
             eps = m(x, torch.tensor([tt], device=dev()))
-            assert rel_err(eps.cpu(), g[f"eps_t{tt}"]) < MODEL_TOL, tt
+            assert record(f"cfg0_eps_t{tt}", rel_err(eps.cpu(), g[f"eps_t{tt}"]), MODEL_TOL) < MODEL_TOL, tt
 
 
 def test_cfg1_eps_vs_reference():
@@ -825,7 +825,7 @@ def test_cfg1_eps_vs_reference():
     x = inp("cfg1.x", (2, 1, 10, 64, 64)).to(dev())
     with torch.no_grad():
         eps = m(x, g["t"].to(dev()))
-    assert rel_err(eps.cpu(), g["eps"]) < MODEL_TOL
+    assert record("cfg1_eps", rel_err(eps.cpu(), g["eps"]), MODEL_TOL) < MODEL_TOL
 
 
 def test_cfg3_cfg_eps_vs_reference():
@@ -834,7 +834,7 @@ def test_cfg3_cfg_eps_vs_reference():
     x, c = inp("cfg3.x", (1, 3, 16, 64, 64)).to(dev()), inp("cfg3.cond", (1, 768)).to(dev())
     with torch.no_grad():
         eps = m.forward_with_cond_scale(x, g["t"].to(dev()), cond=c, cond_scale=2.0)
-    assert rel_err(eps.cpu(), g["eps_cfg2"]) < 2 * MODEL_TOL   # guidance doubles the difference term
+    assert record("cfg3_eps_guided_scale2", rel_err(eps.cpu(), g["eps_cfg2"]), 2 * MODEL_TOL) < 2 * MODEL_TOL   # guidance doubles the difference term
 
 
 @pytest.mark.parametrize("parts", [2, 3, 4])

@@ -29,6 +29,8 @@ def klass(name):
     m = re.search(r"tapgemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         return f"tapgemm<epi={m.group(6)},bn={m.group(2)}>"
+    if "wsconv64_kernel" in name:
+        return "wsconv64"
     for k in ("tattn_fused", "sla_pass1", "sla_pass2", "sla_fold", "rmsnorm_silu"):
         if k in name:
             return k

@@ -57,7 +57,7 @@ def main():
     cands = []
     for c in plan.calls:
         meta = c.args or {}
-        if meta.get("kernel", "").startswith("tapgemm<epi=1,bn=64>"):
+        if meta.get("kernel", "") in ("wsconv64", "tapgemm<epi=1,bn=64>"):
             cands.append(c)
     print(f"{len(cands)} candidate launches")
     worst = 0.0

@@ -80,6 +80,7 @@ _SIGNATURES = {
                                  C.c_void_p, C.c_void_p]),
     "vdmi_tapgemm": (C.c_int, [C.POINTER(TapGemmArgs), C.c_void_p]),
     "vdmi_wsconv_enable": (None, [C.c_int]),
+    "vdmi_wsconv_covers": (C.c_int, [C.c_void_p]),
     "vdmi_attn_core": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vdmi_pack_tattn_elems": (C.c_size_t, [C.c_int, C.c_int]),
@@ -116,6 +117,8 @@ _SIGNATURES = {
     "vdmi_rmsnorm_silu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                     C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_int,
                                     C.c_void_p]),
+    "vdmi_ddpm_step_rng": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p, C.c_int,
+                                     C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "vdmi_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs),
                                  C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
 }

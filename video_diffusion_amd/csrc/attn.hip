@@ -320,13 +320,9 @@ extern "C" int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int head
         if (gpb < 1) gpb = 1;
         const size_t lds = (size_t)gpb * n_tok * row_bytes;
         if (lds <= 150 * 1024) {
-            static bool attr_done = false;
-            if (!attr_done) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_core_lds_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                    return VDMI_E_LAUNCH;
-                attr_done = true;
-            }
+            static std::atomic<uint64_t> attr_mask{0};
+            if (vdmi_set_max_lds(reinterpret_cast<const void*>(attn_core_lds_kernel), attr_mask, 160 * 1024))
+                return VDMI_E_LAUNCH;
             const long long nb = (ngroups + gpb - 1) / gpb;
             if (nb > 0x7fffffffLL) return VDMI_E_SHAPE;
             hipLaunchKernelGGL(attn_core_lds_kernel, dim3((unsigned)nb), dim3(256), lds, static_cast<hipStream_t>(stream),

@@ -389,7 +389,9 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
                                                         const float* __restrict__ z, const int64_t* __restrict__ t,
                                                         vdmi_ddpm_coefs cf, float* __restrict__ out, long long per_sample,
                                                         long long groups_per_sample, int clip, uint64_t seed,
-                                                        uint64_t offset) {
+                                                        uint64_t offset, const uint64_t* __restrict__ rng) {
+    // rng != null: key and counter offset live in device memory (a captured graph then draws what the buffer says)
+    if (rng) { seed = rng[0]; offset = rng[1]; }
     const int b = blockIdx.y;
     const int64_t tb = t[b];
     const float a = cf.sqrt_recip_alphas_cumprod[tb], bb = cf.sqrt_recipm1_alphas_cumprod[tb];
@@ -459,13 +461,9 @@ extern "C" int vdmi_init_conv(const float* x, const float* w, const float* bias,
         if (mlds <= 160 * 1024) {
 #define VDMI_IC_CASE(CT_)                                                                                    \
     if (ct == CT_) {                                                                                         \
-        static bool done = false;                                                                            \
-        if (!done) {                                                                                         \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(init_conv_mfma_kernel<CT_>),               \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)   \
-                return VDMI_E_LAUNCH;                                                                        \
-            done = true;                                                                                     \
-        }                                                                                                    \
+        static std::atomic<uint64_t> attr_mask{0};                                                           \
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(init_conv_mfma_kernel<CT_>), attr_mask, 160 * 1024)) \
+            return VDMI_E_LAUNCH;                                                                            \
         hipLaunchKernelGGL(init_conv_mfma_kernel<CT_>, dim3((tile_grid.x + 3) / 4, tile_grid.y), dim3(256), mlds, \
                            static_cast<hipStream_t>(stream), x, w, bias, static_cast<__bf16*>(out), cin, f,  \
                            h, wd, ksize, nks);                                                               \
@@ -480,13 +478,8 @@ extern "C" int vdmi_init_conv(const float* x, const float* w, const float* bias,
     }
     const size_t lds = ((size_t)cin * ksize * ksize * cout + (size_t)cin * pdim * pdim) * 4;
     if (lds > 160 * 1024) return VDMI_E_LDS;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(init_conv_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return VDMI_E_LAUNCH;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_mask{0};
+    if (vdmi_set_max_lds(reinterpret_cast<const void*>(init_conv_kernel), attr_mask, 160 * 1024)) return VDMI_E_LAUNCH;
     const dim3 grid((unsigned)(((h + 15) / 16) * ((wd + 15) / 16)), (unsigned)(b * f));
     hipLaunchKernelGGL(init_conv_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, w, bias,
                        static_cast<__bf16*>(out), cin, f, h, wd, cout, ksize);
@@ -546,9 +539,9 @@ extern "C" int vdmi_block_scale_shift(const float* emb_silu, int b, int emb_dim,
     return VDMI_OK;
 }
 
-extern "C" int vdmi_ddpm_step(const float* x, const float* eps, const float* z, const int64_t* t,
-                              const vdmi_ddpm_coefs* coefs, float* out, int b, int64_t per_sample, int clip,
-                              uint64_t seed, uint64_t offset, vdmi_stream stream) {
+static int ddpm_step_launch(const float* x, const float* eps, const float* z, const int64_t* t,
+                            const vdmi_ddpm_coefs* coefs, float* out, int b, int64_t per_sample, int clip,
+                            uint64_t seed, uint64_t offset, const uint64_t* rng, vdmi_stream stream) {
     if (!x || !eps || !t || !coefs || !out) return VDMI_E_ARG;
     if (!coefs->sqrt_recip_alphas_cumprod || !coefs->sqrt_recipm1_alphas_cumprod || !coefs->posterior_mean_coef1 ||
         !coefs->posterior_mean_coef2 || !coefs->posterior_log_variance_clipped)
@@ -561,9 +554,22 @@ extern "C" int vdmi_ddpm_step(const float* x, const float* eps, const float* z, 
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)bx, (unsigned)b), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, eps, z, t, *coefs, out, (long long)per_sample, groups, clip,
-                       seed, offset);
+                       seed, offset, rng);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
+}
+
+extern "C" int vdmi_ddpm_step(const float* x, const float* eps, const float* z, const int64_t* t,
+                              const vdmi_ddpm_coefs* coefs, float* out, int b, int64_t per_sample, int clip,
+                              uint64_t seed, uint64_t offset, vdmi_stream stream) {
+    return ddpm_step_launch(x, eps, z, t, coefs, out, b, per_sample, clip, seed, offset, nullptr, stream);
+}
+
+extern "C" int vdmi_ddpm_step_rng(const float* x, const float* eps, const int64_t* t, const vdmi_ddpm_coefs* coefs,
+                                  float* out, int b, int64_t per_sample, int clip, const uint64_t* rng_state,
+                                  vdmi_stream stream) {
+    if (!rng_state || (reinterpret_cast<uintptr_t>(rng_state) & 7u)) return VDMI_E_ARG;
+    return ddpm_step_launch(x, eps, nullptr, t, coefs, out, b, per_sample, clip, 0, 0, rng_state, stream);
 }
 
 // ------------------------------------------------------------------------------------------

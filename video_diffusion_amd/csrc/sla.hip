@@ -442,13 +442,9 @@ extern "C" int vdmi_sla_fused(const void* x, void* y, const void* wpack, const f
     if (lds2 > 160 * 1024) return VDMI_E_LDS;
 #define VDMI_SLA_CASE(C_)                                                                                     \
     if (c == C_) {                                                                                            \
-        static bool attr_done = false;                                                                        \
-        if (!attr_done) {                                                                                     \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(sla_pass2_kernel<C_>),                      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)    \
-                return VDMI_E_LAUNCH;                                                                         \
-            attr_done = true;                                                                                 \
-        }                                                                                                     \
+        static std::atomic<uint64_t> attr_mask{0};                                                            \
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(sla_pass2_kernel<C_>), attr_mask, 160 * 1024))     \
+            return VDMI_E_LAUNCH;                                                                             \
         hipLaunchKernelGGL(sla_pass1_kernel<C_>, grid, dim3(512), 0, st, a);                                  \
         VDMI_LAUNCH_CHECK();                                                                                  \
         hipLaunchKernelGGL(sla_fold_kernel, dim3((unsigned)(frames * heads)), dim3(256),                      \

@@ -785,14 +785,9 @@ int patch_row_cap(const TileCfg& c) {
 
 template <int BM, int BN, int WM, int WN, int BKC, int EPI>
 int launch(const KArgs& k, dim3 grid, size_t lds, hipStream_t stream) {
-    static bool attr_done = false;
+    static std::atomic<uint64_t> attr_mask{0};
     auto fn = tapgemm_kernel<BM, BN, WM, WN, BKC, EPI>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)kLdsMax) != hipSuccess)
-            return VDMI_E_LAUNCH;
-        attr_done = true;
-    }
+    if (vdmi_set_max_lds(reinterpret_cast<const void*>(fn), attr_mask, (int)kLdsMax)) return VDMI_E_LAUNCH;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     hipLaunchKernelGGL(fn, grid, dim3(NT), lds, stream, k);
     VDMI_LAUNCH_CHECK();

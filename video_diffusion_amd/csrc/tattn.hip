@@ -374,13 +374,10 @@ extern "C" int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define VDMI_TATTN_CASE_(C_, RES_, NW_, FOLD_)                                                                \
     if (c == C_ && res == RES_ && fold == FOLD_) {                                                            \
-        static bool attr_done = false;                                                                        \
-        if (!attr_done) {                                                                                     \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<C_, RES_, NW_, FOLD_>),  \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)    \
-                return VDMI_E_LAUNCH;                                                                         \
-            attr_done = true;                                                                                 \
-        }                                                                                                     \
+        static std::atomic<uint64_t> attr_mask{0};                                                            \
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(tattn_fused_kernel<C_, RES_, NW_, FOLD_>), attr_mask, \
+                             160 * 1024))                                                                     \
+            return VDMI_E_LAUNCH;                                                                             \
         hipLaunchKernelGGL((tattn_fused_kernel<C_, RES_, NW_, FOLD_>), dim3(grid), dim3(NW_ * 64), lds, st, a); \
         VDMI_LAUNCH_CHECK();                                                                                  \
         return VDMI_OK;                                                                                       \

@@ -1,6 +1,8 @@
 // Shared device/host helpers for the vdmi kernels (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include "../../include/vdmi.h"
 
@@ -18,6 +20,18 @@ __device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }   // v_cvt
 // y * sigmoid(y) with the hardware exp2 / rcp (1 ulp-class approximations; the result is rounded to bf16)
 __device__ __forceinline__ float silu_f(float y) {
     return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
+}
+
+// hipFuncSetAttribute acts on the current device only, so "already done" is one bit per device in a mask that each
+// call site keeps for its kernel.  Returns 0 when the kernel may use `bytes` of dynamic LDS on the current device.
+static inline int vdmi_set_max_lds(const void* fn, std::atomic<uint64_t>& done_mask, int bytes) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    const uint64_t bit = 1ull << dev;
+    if (done_mask.load(std::memory_order_acquire) & bit) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -1;
+    done_mask.fetch_or(bit, std::memory_order_release);
+    return 0;
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -328,32 +328,45 @@ int g_ws_enabled = -1;
 // environment variable VDMI_WSCONV=0 turns it off for a whole process).
 extern "C" void vdmi_wsconv_enable(int on) { g_ws_enabled = on ? 1 : 0; }
 
-// Runs `A` on the weight-stationary kernel when the launch has its shape.  Returns VDMI_OK when it was launched,
-// 1 when the shape is not covered (the caller then takes the tap-GEMM), a negative status on a launch error.
-int vdmi_wsconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
+// Whether a tap-GEMM launch has the shape the weight-stationary kernel covers (and the kernel is switched on).
+static bool ws_covers(const vdmi_tapgemm_args& A) {
     if (g_ws_enabled < 0) {
         const char* e = std::getenv("VDMI_WSCONV");
         g_ws_enabled = (e && e[0] == '0') ? 0 : 1;
     }
-    if (!g_ws_enabled) return 1;
+    if (!g_ws_enabled) return false;
     const vdmi_tap_pass& m = A.main;
-    if (A.epilogue != VDMI_EPI_NORM_SILU || A.n != 64 || m.c0 != 64 || m.c1 != 0 || m.ntaps != 9 || m.stride != 1) return 1;
+    if (A.epilogue != VDMI_EPI_NORM_SILU || A.n != 64 || m.c0 != 64 || m.c1 != 0 || m.ntaps != 9 || m.stride != 1) return false;
     for (int t = 0; t < 9; ++t)
-        if (m.dy[t] != t / 3 - 1 || m.dx[t] != t % 3 - 1) return 1;
-    if (m.w_group_stride || m.phases > 1 || m.space_to_depth) return 1;
-    if (A.has_res == 1) return 1;
-    if (A.out_mul > 1 || A.out_off_y || A.out_off_x) return 1;
+        if (m.dy[t] != t / 3 - 1 || m.dx[t] != t % 3 - 1) return false;
+    if (m.w_group_stride || m.phases > 1 || m.space_to_depth) return false;
+    if (A.has_res == 1) return false;
+    if (A.out_mul > 1 || A.out_off_y || A.out_off_x) return false;
     const int H = m.in_h, W = m.in_w;
-    if ((W != 64 && W != 32) || A.grid_h != H || A.grid_w != W || A.out_h != H || A.out_w != W) return 1;
+    if ((W != 64 && W != 32) || A.grid_h != H || A.grid_w != W || A.out_h != H || A.out_w != W) return false;
     const int TH = 256 / W;
-    if (H % TH) return 1;
-    if (!A.gain || A.frames_per_batch <= 0 || A.frames % A.frames_per_batch) return 1;
+    if (H % TH) return false;
+    if (!A.gain || A.frames_per_batch <= 0 || A.frames % A.frames_per_batch) return false;
     const long long rows = (long long)A.frames * H * W;
-    if (rows * 128 >= 0x7fffffffLL || rows * A.ldo * 2 >= 0x7fffffffLL) return 1;
-    if (A.has_res == 2 && ((long long)rows * A.ld_res * 2 >= 0x7fffffffLL || A.ld_res % 8 || !A.res_identity)) return 1;
-    if (!aligned16(m.src0) || !aligned16(m.w) || !aligned16(A.out) || A.ldo % 8) return 1;
+    if (rows * 128 >= 0x7fffffffLL || rows * A.ldo * 2 >= 0x7fffffffLL) return false;
+    if (A.has_res == 2 && ((long long)rows * A.ld_res * 2 >= 0x7fffffffLL || A.ld_res % 8 || !A.res_identity)) return false;
+    if (!aligned16(m.src0) || !aligned16(m.w) || !aligned16(A.out) || A.ldo % 8) return false;
     const int nb = A.frames / A.frames_per_batch;
-    if ((long long)nb * A.gain_bstride >= 0x1fffffffLL || (long long)nb * A.shift_bstride >= 0x1fffffffLL) return 1;
+    if ((long long)nb * A.gain_bstride >= 0x1fffffffLL || (long long)nb * A.shift_bstride >= 0x1fffffffLL) return false;
+    return true;
+}
+
+extern "C" int vdmi_wsconv_covers(const vdmi_tapgemm_args* a) { return a && ws_covers(*a) ? 1 : 0; }
+
+// Runs `A` on the weight-stationary kernel when the launch has its shape.  Returns VDMI_OK when it was launched,
+// 1 when the shape is not covered (the caller then takes the tap-GEMM), a negative status on a launch error.
+int vdmi_wsconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
+    if (!ws_covers(A)) return 1;
+    const vdmi_tap_pass& m = A.main;
+    const int H = m.in_h, W = m.in_w;
+    const int TH = 256 / W;
+    const long long rows = (long long)A.frames * H * W;
+    const int nb = A.frames / A.frames_per_batch;
 
     WsArgs k;
     k.in = static_cast<const __bf16*>(m.src0);

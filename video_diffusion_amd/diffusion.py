@@ -100,6 +100,7 @@ class GaussianDiffusion(nn.Module):
         self.noise_source = "torch"
         self.use_hip_graph = True
         self._graphs = {}
+        self._rng = {}
 
     # -- closed forms kept for API compatibility (elementwise torch expressions) ------------
     def q_mean_variance(self, x_start, t):
@@ -141,14 +142,37 @@ class GaussianDiffusion(nn.Module):
         c.posterior_log_variance_clipped = self.posterior_log_variance_clipped.data_ptr()
         return c
 
-    def ddpm_step(self, x, eps, t, noise=None, clip_denoised=True, out=None, seed=0, offset=0):
-        """x_{t-1} from (x_t, eps, noise) in one HIP kernel.  noise=None draws Philox noise in-kernel."""
+    def _rng_state(self, device) -> torch.Tensor:
+        """Device words {seed, offset} of the in-kernel noise: int64 [2], one buffer per device."""
+        key = str(device)
+        if key not in self._rng:
+            self._rng[key] = torch.zeros(2, device=device, dtype=torch.int64)
+        return self._rng[key]
+
+    def reseed_noise(self, device, seed=None) -> int:
+        """New Philox key for the next sampling loop on `device` (drawn from torch's default CPU generator when not
+        given, so torch.manual_seed makes loops reproducible and differently seeded ranks draw different noise).
+        Captured graphs read the key from device memory: every loop, replayed or eager, sees the new one."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._rng_state(device).copy_(torch.tensor([seed, 0], dtype=torch.int64))
+        return seed
+
+    def ddpm_step(self, x, eps, t, noise=None, clip_denoised=True, out=None, seed=0, offset=0, rng_state=None):
+        """x_{t-1} from (x_t, eps, noise) in one HIP kernel.  noise=None draws Philox noise in-kernel, keyed by
+        (seed, offset) or, when rng_state (device int64 [2]) is given, by the two words it holds."""
         if not x.is_cuda:
             raise _lib.VdmiError("ddpm_step runs on the HIP device only")
         x = x.contiguous()
         eps = eps.to(torch.float32).contiguous()
         out = torch.empty_like(x) if out is None else out
         b = x.shape[0]
+        if noise is None and rng_state is not None:
+            check(_lib.lib().vdmi_ddpm_step_rng(
+                x.data_ptr(), eps.data_ptr(), t.data_ptr(), C.byref(self._coefs()), out.data_ptr(), b, x.numel() // b,
+                int(bool(clip_denoised)), rng_state.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                "vdmi_ddpm_step_rng")
+            return out
         check(_lib.lib().vdmi_ddpm_step(
             x.data_ptr(), eps.data_ptr(), None if noise is None else noise.contiguous().data_ptr(),
             t.data_ptr(), C.byref(self._coefs()), out.data_ptr(), b, x.numel() // b, int(bool(clip_denoised)),
@@ -160,8 +184,9 @@ class GaussianDiffusion(nn.Module):
         return self.denoise_fn(x, t, frame_cond_features=frame_cond_features, null_frame_cond_prob=0.)
 
     @torch.inference_mode()
-    def p_sample(self, x, t, frame_cond_features=None, clip_denoised=True, noise=None):
-        # reference: vdp.py:973-1002
+    def p_sample(self, x, t, frame_cond_features=None, clip_denoised=True, noise=None, rng_state=None):
+        # reference: vdp.py:973-1002.  rng_state: with noise_source "philox", the device words a sampling loop keyed
+        # its noise with (None: a fresh key per call)
         predicted_noise = self._predict_noise(x, t, frame_cond_features)
         if clip_denoised and self.use_dynamic_thres:
             # per-sample quantile threshold (off by default): elementwise torch expressions
@@ -172,9 +197,9 @@ class GaussianDiffusion(nn.Module):
             return model_mean + nonzero_mask * (0.5 * model_log_variance).exp() * noise
         if noise is None and self.noise_source == "torch":
             noise = torch.randn_like(x)
-        seed = 0 if noise is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        seed = 0 if (noise is not None or rng_state is not None) else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         return self.ddpm_step(x.to(torch.float32), predicted_noise, t, noise=noise, clip_denoised=clip_denoised,
-                              seed=seed)
+                              seed=seed, rng_state=rng_state)
 
     # -- sampling loop ------------------------------------------------------------------------
     def _graph_runner(self, shape, device):
@@ -183,21 +208,24 @@ class GaussianDiffusion(nn.Module):
         fn = self.denoise_fn
         if not (self.use_hip_graph and isinstance(fn, Unet3D) and not fn.has_cond and not self.use_dynamic_thres):
             return None
-        fn.engine().ensure_packed(device)
-        key = (tuple(shape), str(device), self.noise_source, fn.engine()._packed_key)
+        fn.engine().ensure_packed(device, check_values=True)
+        pack_id = fn.engine().pack_id
+        key = (tuple(shape), str(device), self.noise_source, pack_id)
         if key in self._graphs:
             return self._graphs[key]
+        for old in [k for k in self._graphs if k[3] != pack_id]:      # graphs over weights that were repacked since
+            del self._graphs[old]
         B, Cc, Fr, H, W = shape
         # every step of the loop uses t in [0, num_timesteps): scale/shift rows come from the engine's timestep tables
         plan = fn.engine().plan(B, Fr, H, W, device, time_table=self.num_timesteps)
         z = torch.zeros(shape, device=device, dtype=torch.float32) if self.noise_source == "torch" else None
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        rng = self._rng_state(device)       # read by the captured kernel at every replay: the loop rewrites it per call
 
         def step():
             plan.run()
             if z is not None:
                 z.normal_()
-            self.ddpm_step(plan.x_in, plan.eps_out, plan.t_in, noise=z, clip_denoised=True, out=plan.x_in, seed=seed)
+            self.ddpm_step(plan.x_in, plan.eps_out, plan.t_in, noise=z, clip_denoised=True, out=plan.x_in, rng_state=rng)
 
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -221,7 +249,14 @@ class GaussianDiffusion(nn.Module):
         device = self.betas.device
         b = shape[0]
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
+        if hasattr(self.denoise_fn, "engine"):
+            # once per loop: weights rewritten through `.data` since the last packing are noticed here
+            self.denoise_fn.engine().ensure_packed(device, check_values=True)
         runner = self._graph_runner(shape, device) if noises is None else None
+        rng = None
+        if noises is None and self.noise_source == "philox" and not self.use_dynamic_thres:
+            self.reseed_noise(device)           # one key per loop; graph replay and the eager loop draw the same field
+            rng = self._rng_state(device)
         if runner is not None:
             graph, plan = runner
             plan.x_in.copy_(img)
@@ -231,7 +266,7 @@ class GaussianDiffusion(nn.Module):
             return plan.x_in.clone()
         for k, i in enumerate(reversed(range(0, self.num_timesteps))):
             t = torch.full((b,), i, device=device, dtype=torch.long)
-            img = self.p_sample(img, t, noise=None if noises is None else noises[k].to(device))
+            img = self.p_sample(img, t, noise=None if noises is None else noises[k].to(device), rng_state=rng)
         return img
 
     @torch.inference_mode()
@@ -272,6 +307,7 @@ class GaussianDiffusion(nn.Module):
         rep = 2 if guided else 1
         _, Cc, Fr, H, W = shape
         eng = fn.engine()
+        eng.ensure_packed(device, check_values=True)
         plan = eng.plan(rep * B, Fr, H, W, device, feats.shape[1], time_table=self.num_timesteps)
         plan.ctx_in.copy_(feats.repeat(rep, 1, 1))
         plan.ctx_keep.fill_(1)
@@ -282,7 +318,8 @@ class GaussianDiffusion(nn.Module):
         eps = torch.empty(shape, device=device, dtype=torch.float32)
         t_b = plan.t_in[:B]
         z = torch.zeros(shape, device=device, dtype=torch.float32) if self.noise_source == "torch" else None
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        self.reseed_noise(device)
+        rng = self._rng_state(device)
 
         def step(noise):
             plan.x_in[:B].copy_(state)
@@ -294,7 +331,7 @@ class GaussianDiffusion(nn.Module):
                 torch.add(e_u, e_c - e_u, alpha=frame_cond_scale, out=eps)
             else:
                 eps.copy_(plan.eps_out)
-            self.ddpm_step(state, eps, t_b, noise=noise, clip_denoised=True, out=state, seed=seed)
+            self.ddpm_step(state, eps, t_b, noise=noise, clip_denoised=True, out=state, rng_state=rng)
 
         def drawn_step():
             if z is not None:

@@ -146,7 +146,8 @@ class Plan:
         k = (a.main.c0 + a.main.c1) * a.main.ntaps + ((a.res.c0 + a.res.c1) if a.has_res == 1 else 0)
         bn = 64 if a.tile_bn == 64 else tile_for(a.epilogue, a.n)[0]
         in_rows = a.frames * a.main.in_h * a.main.in_w
-        meta = {"kernel": f"tapgemm<epi={a.epilogue},bn={bn}>", "flops": 2.0 * m * a.n * k,
+        kernel = "wsconv64" if lib.vdmi_wsconv_covers(C.byref(a)) else f"tapgemm<epi={a.epilogue},bn={bn}>"
+        meta = {"kernel": kernel, "flops": 2.0 * m * a.n * k,
                 "bytes": 2.0 * (in_rows * (a.main.c0 + a.main.c1) / (4 if a.main.space_to_depth else 1)
                                 + m * a.n + a.n * k)}
         self._add(lambda s, a=a: lib.vdmi_tapgemm(C.byref(a), s), meta, name, side)
@@ -710,6 +711,9 @@ class UnetEngine:
         self.unet = unet
         self.packed = None
         self._packed_key = None
+        self._packed_values = None
+        self._generation = 0
+        self.pack_id = 0                      # advances at every repack: owners of captured graphs key their caches on it
         self._plans: Dict[Tuple, Plan] = {}
         self._const_cache: Dict[Tuple, object] = {}
 
@@ -720,14 +724,40 @@ class UnetEngine:
 
     def _param_key(self, device):
         rot = self._rotary()
-        return (str(device), getattr(rot, "convention", "half")) + \
+        return (str(device), getattr(rot, "convention", "half"), self._generation) + \
             tuple((p.data_ptr(), p._version) for p in self.unet.parameters())
 
-    def ensure_packed(self, device):
+    def invalidate(self):
+        """The module's weights were changed in a way autograd's version counters do not see (writes through
+        `.data`): repack them before the next forward."""
+        self._generation += 1
+
+    def _values_key(self):
+        """Fingerprint of the parameter VALUES (L1 and L2 norm of every tensor, two multi-tensor launches and one
+        device->host copy).  Version counters miss in-place writes through `.data` (`p.data.copy_`, `p.data.mul_`,
+        the reference's EMA `ma.data = ...` when the allocator hands back the same pointer); the sampling loops,
+        which run thousands of launches on the packed copy, check this once per loop."""
+        ps = [p.detach() for p in self.unet.parameters()]
+        if not ps:
+            return ()
+        with torch.no_grad():
+            n = torch._foreach_norm(ps, 1) + torch._foreach_norm(ps, 2)
+            return tuple(torch.stack([v.double() for v in n]).cpu().tolist())
+
+    def ensure_packed(self, device, check_values: bool = False):
+        """check_values: also compare the parameter values' fingerprint with the packed copy's (costs a host
+        synchronisation; not for use under graph capture)."""
         key = self._param_key(device)
-        if key != self._packed_key:
+        stale = key != self._packed_key
+        vals = None
+        if not stale and check_values:
+            vals = self._values_key()
+            stale = vals != self._packed_values
+        if stale:
             self.packed = self._pack(device)
             self._packed_key = key
+            self._packed_values = self._values_key() if vals is None else vals
+            self.pack_id += 1
             self._plans.clear()
             self._const_cache.clear()
 

@@ -307,6 +307,31 @@ class Unet3D(nn.Module):
             object.__setattr__(self, "_engine", UnetEngine(self))
         return self._engine
 
+    def weights_changed(self):
+        """Tell the HIP engine that parameters were rewritten through `.data` (invisible to autograd's version
+        counters): the packed bf16 copy is rebuilt at the next forward.  Optimizer steps, `load_state_dict` and other
+        in-place operations on the parameters themselves are noticed without this call, and the sampling loops of
+        GaussianDiffusion compare a fingerprint of the values once per loop."""
+        if self._engine is not None:
+            self._engine.invalidate()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # The rotary pairing is not stored in a checkpoint, but the key the checkpoint uses for the frequencies
+        # tells which implementation wrote it: `inv_freq` (buffer) = the half-split class of the reference tree
+        # (video_diffusion_guidance.py:182-198); `freqs` (parameter) = the PyPI rotary_embedding_torch the
+        # reference imports (vdp.py:19), which pairs features (2i, 2i+1).
+        rot_prefix = prefix + "init_temporal_attn.fn.fn.fn.rotary_emb."
+        conv = None
+        if rot_prefix + "freqs" in state_dict:
+            conv = "interleaved"
+        elif rot_prefix + "inv_freq" in state_dict:
+            conv = "half"
+        if conv is not None:
+            for mod in self.modules():
+                if isinstance(mod, RotaryEmbedding):
+                    mod.convention = conv
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def forward_with_cond_scale(self, *args, cond_scale=2., frame_cond_scale=1., **kwargs):
         # reference: vdp.py:731-754
         logits = self.forward(*args, null_cond_prob=0., null_frame_cond_prob=0., **kwargs)

@@ -141,12 +141,16 @@ class EMA:
 
     def update_model_average(self, ma_model, current_model):
         # old * beta + (1 - beta) * new for every parameter, as one multi-tensor lerp per dtype/device group
-        ma = [p.data for p in ma_model.parameters()]
-        cur = [p.data.to(m.dtype) for p, m in zip(current_model.parameters(), ma)]
-        if ma:
-            torch._foreach_lerp_(ma, cur, 1.0 - self.beta)
-            for p in ma_model.parameters():      # in-place update: let weight caches keyed on versions notice
-                p.data = p.data
+        # The in-place update runs on the parameters themselves (under no_grad), so their version counters advance
+        # and the HIP engine of the averaged model repacks its weights before the next sample().
+        ma = list(ma_model.parameters())
+        with torch.no_grad():
+            cur = [p.detach().to(m.dtype) for p, m in zip(current_model.parameters(), ma)]
+            if ma:
+                torch._foreach_lerp_(ma, cur, 1.0 - self.beta)
+        for mod in ma_model.modules():
+            if hasattr(mod, "weights_changed"):
+                mod.weights_changed()
 
     def update_average(self, old, new):
         if old is None:
@@ -250,7 +254,7 @@ class Trainer(object):
             all_milestones = [int(p.stem.split('-')[-1]) for p in Path(self.results_folder).glob('*.pt')]
             assert len(all_milestones) > 0, 'need to have at least one milestone to load'
             milestone = max(all_milestones)
-        data_ = torch.load(str(self.results_folder / f'model-{milestone}.pt'), weights_only=False)
+        data_ = torch.load(str(self.results_folder / f'model-{milestone}.pt'), weights_only=True)
         self.step = data_['step']
         self.model.load_state_dict(data_['model'], **kwargs)
         self.ema_model.load_state_dict(data_['ema'], **kwargs)

@@ -236,7 +236,12 @@ class _ShapeCachedEngine:
     def _plan(self, x: torch.Tensor):
         if x.device.type != "cuda":
             raise _lib.VdmiError("the HIP encoders need a GPU tensor")
-        key = (str(x.device),) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+        # pointers and autograd versions, plus a fingerprint of the values themselves (L1 / L2 norm per tensor: two
+        # multi-tensor launches and one host copy per call): writes through `.data` do not advance a version counter
+        ps = [p.detach() for p in self.module.parameters()]
+        with torch.no_grad():
+            norms = tuple(torch.stack([v.double() for v in torch._foreach_norm(ps, 1) + torch._foreach_norm(ps, 2)]).cpu().tolist()) if ps else ()
+        key = (str(x.device), norms) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
         if key != self._key:
             self._plans.clear()
             self._key = key
