@@ -35,7 +35,8 @@ enum vdmi_status {
     VDMI_E_SHAPE = -2,                /* shape outside what the kernels support       */
     VDMI_E_ALIGN = -3,                /* pointer or leading dimension not 16-byte aligned */
     VDMI_E_LAUNCH = -4,               /* hipLaunchKernel reported an error            */
-    VDMI_E_LDS = -5                   /* tile does not fit the 160 KiB LDS            */
+    VDMI_E_LDS = -5,                  /* tile does not fit the 160 KiB LDS            */
+    VDMI_E_SCRATCH = -6               /* input needs more than the library's static scratch buffer */
 };
 
 const char* vdmi_strerror(int status);            /* HOST */
@@ -190,6 +191,16 @@ int vdmi_xattn_core(const void* q, int ldq, void* o, const void* kvpack_layer, i
 size_t vdmi_groupnorm_workspace_bytes(int nsamples, int64_t rows_per_sample, int c);      /* HOST */
 int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
                         const float* gamma, const float* beta, float eps, void* workspace, vdmi_stream stream);
+/* vdmi_groupnorm_silu without a workspace argument, for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The
+ * partial sums live in a static device array inside the library (VDMI_GROUPNORM_NOALLOC_SCRATCH_BYTES per GPU, held
+ * until the process ends); the call allocates and frees nothing.  Inputs that need more than that, i.e.
+ * vdmi_groupnorm_workspace_bytes(nsamples, rows_per_sample, c) > VDMI_GROUPNORM_NOALLOC_SCRATCH_BYTES, are rejected with
+ * VDMI_E_SCRATCH.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race; calls on one stream do not. */
+#define VDMI_GROUPNORM_NOALLOC_SCRATCH_BYTES (1 << 20)
+int vdmi_groupnorm_silu_noalloc(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
+                                const float* gamma, const float* beta, float eps, vdmi_stream stream);
 /* The general form: act 0 = none, 1 = SiLU; then an optional per-(sample, channel) affine
  * y * post_gain[b][ch] + post_shift[b][ch] (row stride post_bstride; the time-embedding scale + 1 / shift of
  * video_diffusion_guidance.py:378-382), then an optional residual add of bf16 rows [..][ld_res]. */

@@ -104,6 +104,8 @@ _SIGNATURES = {
     "vdmi_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
     "vdmi_groupnorm_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "vdmi_groupnorm_silu_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_float, C.c_void_p]),
     "vdmi_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p]),

@@ -32,6 +32,7 @@ extern "C" const char* vdmi_strerror(int status) {
         case VDMI_E_ALIGN: return "pointer or leading dimension is not 16-byte aligned";
         case VDMI_E_LAUNCH: return "HIP kernel launch failed";
         case VDMI_E_LDS: return "tile does not fit the 160 KiB LDS";
+        case VDMI_E_SCRATCH: return "input needs more than the library's static scratch buffer (use the entry point that takes a workspace)";
         default: return "unknown vdmi status";
     }
 }

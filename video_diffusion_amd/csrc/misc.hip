@@ -1,6 +1,7 @@
 // Small kernels of the denoising path for gfx950: init conv, final 1x1 conv, time/condition
 // embedding, per-block scale/shift tables and the fused DDPM posterior step.
 #include "vdmi_common.h"
+#include <mutex>
 
 namespace {
 
@@ -803,6 +804,42 @@ extern "C" int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64
                                    vdmi_stream stream) {
     return vdmi_groupnorm(x, out, nsamples, rows_per_sample, c, groups, gamma, beta, eps, 1, nullptr, nullptr, 0, nullptr, 0,
                           workspace, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same GroupNorm + SiLU for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses
+// that forbid hipMalloc): the partial sums go to a buffer that is part of the library's code object.  Every GPU the
+// library runs on holds its own copy of the array at its own address; the array's name is only a host-side handle,
+// so the device address is looked up once per device (with that device current) and kept.
+// ------------------------------------------------------------------------------------------
+static __device__ __align__(256) float vdmi_gn_scratch[VDMI_GROUPNORM_NOALLOC_SCRATCH_BYTES / sizeof(float)];
+
+static float* gn_scratch_device_ptr(int* status) {
+    static std::mutex mu;
+    static float* ptr_of_device[64] = {nullptr};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *status = VDMI_E_LAUNCH; return nullptr; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr_of_device[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(vdmi_gn_scratch)) != hipSuccess || !p) { *status = VDMI_E_LAUNCH; return nullptr; }
+        ptr_of_device[dev] = static_cast<float*>(p);
+    }
+    *status = VDMI_OK;
+    return ptr_of_device[dev];
+}
+
+extern "C" int vdmi_groupnorm_silu_noalloc(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
+                                           const float* gamma, const float* beta, float eps, vdmi_stream stream) {
+    const size_t need = vdmi_groupnorm_workspace_bytes(nsamples, rows_per_sample, c);
+    if (need == 0) return VDMI_E_SHAPE;
+    if (need > (size_t)VDMI_GROUPNORM_NOALLOC_SCRATCH_BYTES) return VDMI_E_SCRATCH;
+    int st = VDMI_OK;
+    float* scratch = gn_scratch_device_ptr(&st);
+    if (!scratch) return st;
+    // the first pass overwrites every partial sum the second pass reads: nothing has to start at zero
+    return vdmi_groupnorm(x, out, nsamples, rows_per_sample, c, groups, gamma, beta, eps, 1, nullptr, nullptr, 0, nullptr, 0,
+                          scratch, stream);
 }
 
 extern "C" int vdmi_temporal_dwconv(const void* x, int ldx, void* out, int ldo, int b, int f, int64_t hw, int c, int k,
