@@ -8,7 +8,7 @@ out=$root/gpurun_out/prof
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-B="$root/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+B="$root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-full-loop"
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $out/kt_$tag -o kt -- python3 $B > $out/kt_$tag.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $out/fetch_$tag -o pmc -- python3 $B > $out/fetch_$tag.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $out/write_$tag -o pmc -- python3 $B > $out/write_$tag.log 2>&1
