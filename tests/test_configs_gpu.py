@@ -8,7 +8,7 @@ Reference arithmetic: video_diffusion_pytorch/video_diffusion_pytorch.py:731-754
 import pytest
 import torch
 
-from tests.helpers import CFG0, CFG1, CFG3, TINY, golden, inp, make_unet, record, rel_err
+from tests.helpers import CFG0, CFG1, CFG3, TINY, TINY_COND, golden, inp, make_unet, record, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -171,6 +171,41 @@ def test_weights_rewritten_through_data_are_repacked():
     torch.manual_seed(3)
     c = gd.p_sample_loop(shape, x_T=x_T)
     assert torch.equal(c, a)
+
+
+def test_cond_sample_loop_is_the_two_pass_guided_loop():
+    """configs[3] harness: the guided loop over a doubled batch (rows B.. take the null embedding) equals the loop
+    that evaluates the conditional and the null-conditioned epsilon in two passes (forward_with_cond_scale of the
+    reference, vdp.py:731-748, then the posterior step :973-1002), and its graph replay equals its eager run."""
+    from video_diffusion_amd import GaussianDiffusion
+    m = make_unet(**TINY_COND).to(dev())
+    T = 6
+    gd = GaussianDiffusion(m, torch.nn.Identity(), image_size=12, num_frames=4, channels=3, timesteps=T).to(dev())
+    gd.noise_source = "philox"
+    shape = (2, 3, 4, 12, 12)
+    x_T, cond = inp("cl.xT", shape).to(dev()), inp("cl.cond", (2, 16)).to(dev())
+    noises = [inp(f"cl.z{k}", shape).to(dev()) for k in range(T)]
+    a = gd.cond_sample_loop(shape, cond, 2.0, x_T=x_T, noises=noises)
+    x = x_T.clone()
+    with torch.no_grad():
+        for k, i in enumerate(reversed(range(T))):
+            t = torch.full((2,), i, device=dev(), dtype=torch.long)
+            e_c = m(x, t, cond=cond, null_cond_prob=0.)
+            e_n = m(x, t, cond=cond, null_cond_prob=1.)
+            x = gd.ddpm_step(x, e_n + (e_c - e_n) * 2.0, t, noise=noises[k])
+            g = m.forward_with_cond_scale(x, t, cond=cond, cond_scale=2.0)       # one doubled pass
+            e_c2, e_n2 = m(x, t, cond=cond, null_cond_prob=0.), m(x, t, cond=cond, null_cond_prob=1.)
+            assert rel_err(g.cpu(), (e_n2 + (e_c2 - e_n2) * 2.0).cpu()) < 1e-6
+    assert torch.isfinite(a).all() and rel_err(a.cpu(), x.cpu()) < 1e-5
+    assert torch.equal(a, gd.p_sample_loop(shape, x_T=x_T, noises=noises, cond=cond, cond_scale=2.0))
+    outs = []
+    for use_graph in (True, False):
+        torch.manual_seed(9)
+        gd.use_hip_graph = use_graph
+        outs.append(gd.cond_sample_loop(shape, cond, 2.0, x_T=x_T))
+    assert torch.equal(outs[0], outs[1])
+    u = gd.cond_sample_loop(shape, cond, 1.0, x_T=x_T, noises=noises)                # unguided: one pass per step
+    assert not torch.equal(u, a)
 
 
 def test_sla_pass1_beside_fold_kernels_on_another_stream():

@@ -9,6 +9,9 @@ Workloads (random-init weights, synthetic inputs):
              previous frames (context = prev * (S/4)^2 tokens of 512 features), frame_cond_scale=1.5: one step =
              one pass over the doubled batch + guidance + posterior step, replayed as a HIP graph.
   vae        VAE(channels=3, latent_dim=4, base_dim=64): decode (B,4,F,S,S) -> (B,3,F,8S,8S), encode back.
+  textcfg    Unet3D(dim=128, dim_mults=(1,2,4,8), channels=3, cond_dim=768) on (--cfg-batch, 3, 16, 64, 64) with
+             classifier-free guidance cond_scale=2: one step = one pass over the doubled batch (rows B.. take the
+             null embedding) + guidance + posterior step, replayed as a HIP graph; with its roofline block.
 """
 import argparse
 import json
@@ -51,6 +54,65 @@ def per_call(calls, reps=5):
     return out
 
 
+def text_cfg(args, dev):
+    """Text-conditioned model with classifier-free guidance (the guided forward of reference vdp.py:731-748 inside
+    the posterior-step loop), one JSON line with the roofline of its dominant matrix-core kernel class."""
+    from video_diffusion_amd import GaussianDiffusion, Unet3D
+    B, F, S = args.cfg_batch, 16, 64
+    torch.manual_seed(0)
+    unet = Unet3D(dim=128, dim_mults=(1, 2, 4, 8), channels=3, cond_dim=768).to(dev).eval()
+    gd = GaussianDiffusion(unet, torch.nn.Identity(), image_size=S, num_frames=F, channels=3, timesteps=1000).to(dev)
+    gd.noise_source = "philox"
+    shape = (B, 3, F, S, S)
+    cond = torch.randn(B, 768, device=dev)
+    t0 = time.perf_counter()
+    gd.cond_sample_loop(shape, cond, 2.0, steps=3)                  # builds plan + graph
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    gd.cond_sample_loop(shape, cond, 2.0, steps=3)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    gd.cond_sample_loop(shape, cond, 2.0, steps=3 + args.steps)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    ms = ((t3 - t2) - (t2 - t1)) / args.steps * 1e3
+    plan = unet.engine().plan(2 * B, F, S, S, dev)
+    stream = torch.cuda.current_stream()
+    evs, reps = [], 3
+    for _ in range(reps):
+        for c in plan.calls:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            assert c.fn(stream.cuda_stream) == 0
+            e1.record(stream)
+            evs.append((c, e0, e1))
+    torch.cuda.synchronize()
+    cl = {}
+    for c, e0, e1 in evs:
+        meta = c.args or {}
+        d = cl.setdefault(meta.get("kernel", c.name.split(".")[-1]), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+        d["ms"] += e0.elapsed_time(e1) / reps
+        d["flops"] += meta.get("flops", 0.0) / reps
+        d["bytes"] += meta.get("bytes", 0.0) / reps
+        d["n"] += 1
+    dom_key = max((k for k in cl if cl[k]["flops"] > 0), key=lambda k: cl[k]["ms"])
+    dom = cl[dom_key]
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    total_flops = sum(v["flops"] for v in cl.values())
+    print(json.dumps({
+        "workload": f"text-conditioned CFG x2.0 (doubled batch): Unet3D(dim=128, cond_dim=768) on {shape}, one guided denoise step",
+        "ms_per_step": round(ms, 3), "guided_samples_per_s_at_T1000": round(B / (ms * 1e-3) / 1000, 4),
+        "first_call_s": round(t1 - t0, 2), "launch": "hip-graph replay", "dtype": "bf16",
+        "step_tflops": round(total_flops / (ms * 1e-3) / 1e12, 1),
+        "roofline": {"bound": "mfma", "kernel": dom_key, "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": round(ach / 2500.0, 4), "launches_per_step": dom["n"] // reps,
+                     "avg_launch_ms": round(dom["ms"] / (dom["n"] // reps), 4), "traffic": None},
+        "classes_ms": {k: {"ms": round(v["ms"], 4), "launches": v["n"] // reps,
+                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
+                       for k, v in sorted(cl.items(), key=lambda kv: -kv[1]["ms"])},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
@@ -58,13 +120,22 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--prev", type=int, default=4)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--cfg-batch", type=int, default=8)
+    ap.add_argument("--only", default="", help="comma list of workloads to run (default: all)")
     args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    want = lambda name: not only or name in only
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     from video_diffusion_amd import GaussianDiffusion, Unet3D, VAE
     from video_diffusion_amd.vae import FrameConditioningEncoder
     B, F, S = args.batch, args.frames, args.latent
     torch.manual_seed(0)
+
+    if want("textcfg"):
+        text_cfg(args, dev)
+    if not (want("framecond") or want("vae")):
+        return
 
     # ---- frame-conditioned guided step ------------------------------------------------------------------
     unet = Unet3D(dim=64, dim_mults=(1, 2, 4, 8), channels=4).to(dev).eval()

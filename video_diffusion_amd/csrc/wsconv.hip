@@ -288,8 +288,17 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
         WS_ACC(7, ts);
     };
 
+    // Tile of this workgroup in round r of the persistent loop.  Workgroups are dealt to the 8 XCDs round-robin, so
+    // within a full round the workgroups of one XCD (blockIdx.x % 8 equal) take a run of consecutive tiles: the bands
+    // of a frame, whose halo rows they share, then meet in that XCD's L2 instead of being fetched by two XCDs.
     const int stride = gridDim.x;
-    int tile = blockIdx.x;
+    auto tile_of = [&](int r) -> int {
+        const int base = r * stride;
+        if ((stride & 7) == 0 && base + stride <= a.ntiles)
+            return base + (int)(blockIdx.x & 7) * (stride >> 3) + (int)(blockIdx.x >> 3);
+        return base + (int)blockIdx.x;
+    };
+    int tile = tile_of(0);
     __syncthreads();                       // bias / parameter / flag initialisation
     if (tile < a.ntiles) issue_patch(tile, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -297,8 +306,9 @@ __global__ __launch_bounds__(512) void wsconv64_kernel(const WsArgs a) {
 
     ts = WS_T();
     int k = 0;
-    for (; tile < a.ntiles; tile += stride, ++k) {
-        if (tile + stride < a.ntiles) issue_patch(tile + stride, (k + 1) & 1, (k + 1) % 3);
+    for (int nxt; tile < a.ntiles; tile = nxt, ++k) {
+        nxt = tile_of(k + 1);
+        if (nxt < a.ntiles) issue_patch(nxt, (k + 1) & 1, (k + 1) % 3);
         WS_ACC(0, ts);
         if constexpr (RES) issue_res(tile);
         init_acc();

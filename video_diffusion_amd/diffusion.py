@@ -213,7 +213,7 @@ class GaussianDiffusion(nn.Module):
         key = (tuple(shape), str(device), self.noise_source, pack_id)
         if key in self._graphs:
             return self._graphs[key]
-        for old in [k for k in self._graphs if k[3] != pack_id]:      # graphs over weights that were repacked since
+        for old in [k for k in self._graphs if k[0] != "cond" and k[3] != pack_id]:      # graphs over weights repacked since
             del self._graphs[old]
         B, Cc, Fr, H, W = shape
         # every step of the loop uses t in [0, num_timesteps): scale/shift rows come from the engine's timestep tables
@@ -243,9 +243,13 @@ class GaussianDiffusion(nn.Module):
         return runner
 
     @torch.inference_mode()
-    def p_sample_loop(self, shape, x_T=None, noises=None):
+    def p_sample_loop(self, shape, x_T=None, noises=None, cond=None, cond_scale=1.):
         """reference: vdp.py:1004-1014.  x_T / noises (one tensor per step, in execution order) may
-        be injected for parity checks; by default they are drawn as the reference draws them."""
+        be injected for parity checks; by default they are drawn as the reference draws them.
+        cond / cond_scale: the condition vectors of a Unet3D(cond_dim=...) and the classifier-free guidance scale
+        of its forward_with_cond_scale (reference vdp.py:731-748); see cond_sample_loop."""
+        if cond is not None:
+            return self.cond_sample_loop(shape, cond, cond_scale, x_T=x_T, noises=noises)
         device = self.betas.device
         b = shape[0]
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
@@ -268,6 +272,107 @@ class GaussianDiffusion(nn.Module):
             t = torch.full((b,), i, device=device, dtype=torch.long)
             img = self.p_sample(img, t, noise=None if noises is None else noises[k].to(device), rng_state=rng)
         return img
+
+    def _cond_runner(self, shape, device, rep):
+        """Plan over rep * B samples, state / epsilon buffers and (with use_hip_graph) the captured step of the
+        condition-vector loop; cached per shape like the unconditional runner."""
+        fn = self.denoise_fn
+        eng = fn.engine()
+        eng.ensure_packed(device, check_values=True)
+        key = ("cond", tuple(shape), rep, str(device), self.noise_source, eng.pack_id, bool(self.use_hip_graph))
+        if key in self._graphs:
+            return self._graphs[key]
+        for old in [k for k in self._graphs if k[0] == "cond" and k[5] != eng.pack_id]:
+            del self._graphs[old]
+        B, Cc, Fr, H, W = shape
+        plan = eng.plan(rep * B, Fr, H, W, device)      # the condition enters the time embedding: no timestep tables
+        state = torch.zeros(shape, device=device, dtype=torch.float32)
+        eps = torch.empty(shape, device=device, dtype=torch.float32)
+        scale = torch.ones((), device=device, dtype=torch.float32)     # guidance scale, read by the captured step
+        z = torch.zeros(shape, device=device, dtype=torch.float32) if self.noise_source == "torch" else None
+        rng = self._rng_state(device)
+        t_b = plan.t_in[:B]
+
+        def step(noise):
+            plan.x_in[:B].copy_(state)
+            if rep == 2:
+                plan.x_in[B:].copy_(state)
+            plan.run()
+            if rep == 2:
+                e_c, e_u = plan.eps_out[:B], plan.eps_out[B:]
+                torch.addcmul(e_u, e_c - e_u, scale, out=eps)           # null + (cond - null) * scale
+            else:
+                eps.copy_(plan.eps_out)
+            self.ddpm_step(state, eps, t_b, noise=noise, clip_denoised=True, out=state, rng_state=rng)
+
+        def drawn_step():
+            if z is not None:
+                z.normal_()
+            step(z)
+
+        graph = None
+        if self.use_hip_graph:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                plan.t_in.fill_(0)
+                drawn_step()                # warm-up outside capture
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                drawn_step()
+        runner = dict(plan=plan, state=state, scale=scale, step=step, drawn_step=drawn_step, graph=graph)
+        self._graphs[key] = runner
+        return runner
+
+    @torch.inference_mode()
+    def cond_sample_loop(self, shape, cond, cond_scale=1.0, x_T=None, noises=None, steps=None):
+        """The denoising loop of a model with a condition vector: every step evaluates
+        forward_with_cond_scale(x, t, cond=cond, cond_scale=cond_scale) (reference vdp.py:731-748; the reference's own
+        sampler never passes a condition, this is the loop its guided forward is written for) and takes the
+        static-clip posterior step (reference vdp.py:973-1002).
+
+        With the HIP Unet3D the conditional and the null-conditioned evaluation of a guided step run as ONE pass over a
+        doubled batch (rows B.. take the null embedding), and each step replays one captured HIP graph.  x_T / noises
+        (one tensor per step, in execution order) may be injected for parity checks; `steps` stops early."""
+        from .modules import Unet3D
+        device = self.betas.device
+        fn = self.denoise_fn
+        B = shape[0]
+        cond = cond.to(device=device, dtype=torch.float32)
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
+        guided = cond_scale != 1.0
+        order = list(reversed(range(0, self.num_timesteps)))[:steps]
+        if not (isinstance(fn, Unet3D) and fn.has_cond and not self.use_dynamic_thres):
+            for k, i in enumerate(order):       # any other denoiser: call for call
+                t = torch.full((B,), i, device=device, dtype=torch.long)
+                nz = None if noises is None else noises[k].to(device)
+                e = fn.forward_with_cond_scale(img, t, cond=cond, cond_scale=cond_scale)
+                nz = torch.randn_like(img) if nz is None else nz
+                img = self.ddpm_step(img, e, t, noise=nz, clip_denoised=True)
+            return img
+        rep = 2 if guided else 1
+        r = self._cond_runner(shape, device, rep)
+        plan = r["plan"]
+        plan.cond_in.copy_(cond.repeat(rep, 1))
+        plan.null_mask.fill_(0)
+        if guided:
+            plan.null_mask[B:].fill_(1)
+        plan.focus_in.fill_(0)
+        r["scale"].fill_(float(cond_scale))
+        r["state"].copy_(img)
+        if noises is None and self.noise_source == "philox":
+            self.reseed_noise(device)
+        for k, i in enumerate(order):
+            plan.t_in.fill_(i)
+            if noises is not None:
+                r["step"](noises[k].to(device=device, dtype=torch.float32).contiguous())
+            elif r["graph"] is not None:
+                r["graph"].replay()
+            else:
+                r["drawn_step"]()
+        return r["state"].clone()
 
     @torch.inference_mode()
     def frame_cond_sample_loop(self, shape, frame_cond_features, frame_cond_scale=1.0, x_T=None, noises=None,

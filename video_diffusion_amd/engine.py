@@ -1046,16 +1046,21 @@ class UnetEngine:
         key = (B, F, H, W, str(device), L, focus, time_table)
         if key not in self._plans:
             parts = batch_parts(B)
-            if parts > 1:
-                self._plans[key] = SplitPlan(self, B, F, H, W, device, parts, L=L, focus=focus, time_table=time_table)
-            else:
-                self._plans[key] = self.plan_class(self, B, F, H, W, device, L=L, focus=focus, time_table=time_table)
+            # plans are cached and reused by callers in and out of inference mode: their buffers must be ordinary
+            # tensors (an inference tensor cannot be written outside inference mode)
+            with torch.inference_mode(False):
+                if parts > 1:
+                    self._plans[key] = SplitPlan(self, B, F, H, W, device, parts, L=L, focus=focus, time_table=time_table)
+                else:
+                    self._plans[key] = self.plan_class(self, B, F, H, W, device, L=L, focus=focus, time_table=time_table)
         return self._plans[key]
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, time: torch.Tensor, cond=None, null_cond_prob: float = 0.,
                 frame_cond_features=None, null_frame_cond_prob: float = 0., focus_present_mask=None,
-                prob_focus_present: float = 0.) -> torch.Tensor:
+                prob_focus_present: float = 0., null_cond_mask=None) -> torch.Tensor:
+        """null_cond_mask (bool / uint8 [B]): which samples take the null condition embedding, instead of drawing the
+        mask with probability null_cond_prob (a guided evaluation runs its two branches as one doubled batch)."""
         if not x.is_cuda:
             raise _lib.VdmiError("Unet3D runs on the HIP device only (no CPU fallback); move the module and inputs to 'cuda'")
         u = self.unet
@@ -1095,7 +1100,9 @@ class UnetEngine:
             plan.focus_in.copy_((torch.rand(B, device=x.device) < prob_focus_present).to(torch.uint8))
         if u.has_cond:
             plan.cond_in.copy_(cond.to(torch.float32))
-            if null_cond_prob == 1:
+            if null_cond_mask is not None:
+                plan.null_mask.copy_(null_cond_mask.to(device=x.device, dtype=torch.uint8))
+            elif null_cond_prob == 1:
                 plan.null_mask.fill_(1)
             elif null_cond_prob == 0:
                 plan.null_mask.fill_(0)

@@ -334,9 +334,27 @@ class Unet3D(nn.Module):
 
     def forward_with_cond_scale(self, *args, cond_scale=2., frame_cond_scale=1., **kwargs):
         # reference: vdp.py:731-754
-        logits = self.forward(*args, null_cond_prob=0., null_frame_cond_prob=0., **kwargs)
         if cond_scale == 1 and frame_cond_scale == 1:
-            return logits
+            return self.forward(*args, null_cond_prob=0., null_frame_cond_prob=0., **kwargs)
+        text_only = self.has_cond and cond_scale != 1 and not (self.has_frame_cross_attn and frame_cond_scale != 1)
+        if text_only and not torch.is_grad_enabled() and len(args) == 2 and args[0].is_cuda and kwargs.get("cond") is not None:
+            # the conditional and the null-conditioned evaluation as ONE pass over a doubled batch: samples never
+            # interact, so each half is what its own pass would give
+            x, time = args[0], args[1]
+            B = x.shape[0]
+            rep = lambda v: None if v is None else torch.cat([v, v], dim=0)
+            mask = torch.zeros(2 * B, dtype=torch.uint8, device=x.device)
+            mask[B:] = 1
+            kw = dict(kwargs)
+            kw["cond"] = rep(kwargs["cond"])
+            for k in ("frame_cond_features", "focus_present_mask"):
+                if kw.get(k) is not None:
+                    kw[k] = rep(kw[k])
+            both = self.engine().forward(rep(x), rep(time), null_cond_prob=0., null_frame_cond_prob=0.,
+                                         null_cond_mask=mask, **kw)
+            logits, null_logits = both[:B], both[B:]
+            return null_logits + (logits - null_logits) * cond_scale
+        logits = self.forward(*args, null_cond_prob=0., null_frame_cond_prob=0., **kwargs)
         if self.has_cond and cond_scale != 1:
             null_logits = self.forward(*args, null_cond_prob=1., null_frame_cond_prob=0., **kwargs)
             logits = null_logits + (logits - null_logits) * cond_scale
