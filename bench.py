@@ -310,9 +310,21 @@ def main():
                             "avg_launch_ms": round(d_ms, 4),
                             "algorithmic_bytes_per_launch": d_bytes}
         roofline["hbm_classes"] = hbm
+        # traffic_gbs: HBM-side bytes of the class from the committed counter passes (sla_fused = its three kernels)
+        # over the launch time measured here: how close a class runs to the memory side of its roofline
+        tj = {}
+        try:
+            tj = json.load(open(tpath))
+        except Exception:
+            pass
+        per_launch = dict(tj)
+        if all(k in tj for k in ("sla_pass1", "sla_fold", "sla_pass2")):
+            per_launch["sla_fused"] = tj["sla_pass1"] + tj["sla_fold"] + tj["sla_pass2"]
         breakdown = {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches": v["launches_per_step"],
                          "tflops": round(v["flops_per_step"] / (v["ms_per_step"] * 1e-3) / 1e12, 1) if v["flops_per_step"] else None,
-                         "alg_gbs": round(v["bytes_per_step"] / (v["ms_per_step"] * 1e-3) / 1e9, 1) if v["bytes_per_step"] else None}
+                         "alg_gbs": round(v["bytes_per_step"] / (v["ms_per_step"] * 1e-3) / 1e9, 1) if v["bytes_per_step"] else None,
+                         "traffic_gbs": round(per_launch[k] * v["launches_per_step"] / (v["ms_per_step"] * 1e-3) / 1e9, 1)
+                         if isinstance(per_launch.get(k), (int, float)) else None}
                      for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["ms_per_step"])}
 
     if rank == 0:

@@ -14,6 +14,7 @@ import sys
 
 
 def per_kernel(dbpath, counter):
+    """{kernel name: (sum of the counter over its dispatches, number of dispatches)}"""
     db = sqlite3.connect(dbpath)
     acc, n = collections.defaultdict(float), collections.defaultdict(set)
     for name, cname, val, did in db.execute(
@@ -22,7 +23,7 @@ def per_kernel(dbpath, counter):
             continue
         acc[name] += val
         n[name].add(did)
-    return {k: acc[k] / len(n[k]) for k in acc}
+    return {k: (acc[k], len(n[k])) for k in acc}
 
 
 def klass(name):
@@ -31,7 +32,8 @@ def klass(name):
         return f"tapgemm<epi={m.group(6)},bn={m.group(2)}>"
     if "wsconv64_kernel" in name:
         return "wsconv64"
-    for k in ("tattn_fused", "sla_pass1", "sla_pass2", "sla_fold", "rmsnorm_silu"):
+    for k in ("tattn_fused", "sla_pass1", "sla_pass2", "sla_fold", "rmsnorm_silu", "ddpm_step", "attn_core_lds",
+              "xattn_core", "init_conv_mfma", "final_conv"):
         if k in name:
             return k
     return None
@@ -40,19 +42,23 @@ def klass(name):
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {}
-for name in fetch:
+for name, (fsum, fn) in fetch.items():
     k = klass(name)
     if k is None:
         continue
-    d = out.setdefault(k, {"fetch_bytes_per_launch": 0.0, "write_bytes_per_launch": 0.0, "kernels": []})
-    # several tile shapes can share a class: keep the largest (it is the class's dominant shape)
-    fb = fetch[name] * 1024 * 2
-    wb = write.get(name, 0.0) * 1024
-    if fb + wb > d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"]:
-        d["fetch_bytes_per_launch"], d["write_bytes_per_launch"] = fb, wb
-    d["kernels"].append(name)
-res = {k: round(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for k, v in out.items()}
-res["_detail"] = out
-res["_note"] = "bytes per launch, averaged over the launches of the class's kernel; FETCH_SIZE doubled (gfx950)"
+    wsum, wn = write.get(name, (0.0, fn))
+    d = out.setdefault(k, {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches": 0, "kernels": {}})
+    fb, wb = fsum * 1024 * 2, wsum * 1024 * (fn / wn if wn else 0.0)     # write pass scaled to the fetch pass's dispatch count
+    d["fetch_bytes"] += fb
+    d["write_bytes"] += wb
+    d["launches"] += fn
+    d["kernels"][name] = {"launches": fn, "fetch_bytes_per_launch": fb / fn, "write_bytes_per_launch": wb / fn}
+# per class: bytes per launch averaged over every launch of the class in the profiled run (all its kernels and shapes)
+res = {k: round((v["fetch_bytes"] + v["write_bytes"]) / v["launches"]) for k, v in out.items()}
+res["_detail"] = {k: {"fetch_bytes_per_launch": v["fetch_bytes"] / v["launches"],
+                      "write_bytes_per_launch": v["write_bytes"] / v["launches"], "kernels": v["kernels"]}
+                  for k, v in out.items()}
+res["_note"] = ("bytes per launch, averaged over all launches of the class (every kernel and shape of it) in the profiled "
+                "bench run; FETCH_SIZE doubled (gfx950)")
 json.dump(res, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1))
