@@ -406,27 +406,22 @@ int vdmi_wsconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     if (const char* dp = std::getenv("VDMI_DIAG_PTR")) k.diag = reinterpret_cast<unsigned long long*>(std::strtoull(dp, nullptr, 0));
 #endif
 
-    int dev = 0, ncu = 256;
-    static int cu_count[64] = {0};
-    static bool attr_set[64][4] = {};
+    int dev = 0;
+    static std::atomic<int> cu_count[64];             // per device, 0 until asked (zero-initialised)
+    static std::atomic<uint64_t> attr_mask[4];        // per kernel variant, one bit per device
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VDMI_E_LAUNCH;
-    if (!cu_count[dev]) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return VDMI_E_LAUNCH;
-        cu_count[dev] = v;
+    int ncu = cu_count[dev].load(std::memory_order_relaxed);
+    if (!ncu) {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return VDMI_E_LAUNCH;
+        cu_count[dev].store(ncu, std::memory_order_relaxed);
     }
-    ncu = cu_count[dev];
     const int grid = k.ntiles < ncu ? k.ntiles : ncu;
     const int wi = (W == 64 ? 0 : 1) + (k.res ? 2 : 0);
     const int PW = W + 2, PH = TH + 2, ninstr = (PH * PW + 7) / 8;
     const size_t lds = (size_t)2 * ninstr * 1024 + 8 * 4096 + 4096 + 3 * 512 + 256 + 64;
     auto fn = W == 64 ? (k.res ? wsconv64_kernel<64, true> : wsconv64_kernel<64, false>)
                       : (k.res ? wsconv64_kernel<32, true> : wsconv64_kernel<32, false>);
-    if (!attr_set[dev][wi]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return VDMI_E_LAUNCH;
-        attr_set[dev][wi] = true;
-    }
+    if (vdmi_set_max_lds(reinterpret_cast<const void*>(fn), attr_mask[wi], 160 * 1024)) return VDMI_E_LAUNCH;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream, k);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
