@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void sla_pass1_kernel(const SlaArgs a) {
             float tmax = kacc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, kacc[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            tmax = xhalf_max(tmax);
             if (__any(tmax > m_run)) {    // rescale only when some feature's maximum moved (rare after the first chunks)
                 const float m_new = fmaxf(m_run, tmax);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void sla_pass1_kernel(const SlaArgs a) {
                 kacc[r] = e;
                 lsum += e;
             }
-            lsum += __shfl_xor(lsum, 32);
+            lsum = xhalf_add(lsum);
             l_run += lsum;
             // ctx^T[e][d] += sum_n V[n][e] * E[n][d]
             ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vacc, 0), acc_frag(kacc, 0), ctx, 0, 0, 0);
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(512, 2) void sla_pass2_kernel(const SlaArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
         }
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
+        s1 = xhalf_add(s1);
+        s2 = xhalf_add(s2);
         const float mean = s1 * (1.0f / C);
         const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
 #pragma unroll
@@ -312,11 +312,11 @@ __global__ __launch_bounds__(512, 2) void sla_pass2_kernel(const SlaArgs a) {
             float mx = q[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, q[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xhalf_max(mx);
             float sum = 0.f;      // Wq rows carry a factor log2 e (host packing)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { q[r] = __builtin_amdgcn_exp2f(q[r] - mx); sum += q[r]; }
-            sum += __shfl_xor(sum, 32);
+            sum = xhalf_add(sum);
             const float inv = a.q_scale / sum;
 #pragma unroll
             for (int r = 0; r < 16; ++r) q[r] *= inv;

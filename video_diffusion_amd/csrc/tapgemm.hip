@@ -462,7 +462,7 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ss[j] += acc[i][j][r] * acc[i][j][r];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) ss[j] += __shfl_xor(ss[j], 32);
+        for (int j = 0; j < NJ; ++j) ss[j] = xhalf_add(ss[j]);
         if constexpr (NWN > 1) {
             __syncthreads();
             if (lane < 32) {
@@ -581,11 +581,11 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
                         float m = acc[i][j][0];
 #pragma unroll
                         for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
-                        m = fmaxf(m, __shfl_xor(m, 32));
+                        m = xhalf_max(m);
                         float sum = 0.f;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) { const float e = __expf(acc[i][j][r] - m); acc[i][j][r] = e; sum += e; }
-                        sum += __shfl_xor(sum, 32);
+                        sum = xhalf_add(sum);
                         const float inv = a.q_scale / sum;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;

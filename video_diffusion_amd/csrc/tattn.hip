@@ -171,8 +171,8 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
         }
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
+        s1 = xhalf_add(s1);
+        s2 = xhalf_add(s2);
         const float mean = s1 * (1.0f / C);
         const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
 #pragma unroll
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
                     }
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xhalf_max(mx);
             float lsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
                 st[r] = p;
                 lsum += p;
             }
-            lsum += __shfl_xor(lsum, 32);
+            lsum = xhalf_add(lsum);
             // ---- O^T = V^T P^T ---------------------------------------------------------------------
             f32x16 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(v, 0), acc_frag(st, 0), zero, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(v, 1), acc_frag(st, 1), o, 0, 0, 0);

@@ -22,6 +22,18 @@ __device__ __forceinline__ float silu_f(float y) {
     return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
 }
 
+// Sum / maximum of a value with the lane 32 away (the other half of the wave64), the same in both lanes.
+// v_permlane32_swap is a vector instruction; __shfl_xor(x, 32) compiles to ds_bpermute_b32, an LDS round trip whose
+// wait (lgkmcnt) also waits for every LDS read in flight.
+__device__ __forceinline__ float xhalf_add(float v) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+
 // hipFuncSetAttribute acts on the current device only, so "already done" is one bit per device in a mask that each
 // call site keeps for its kernel.  Returns 0 when the kernel may use `bytes` of dynamic LDS on the current device.
 static inline int vdmi_set_max_lds(const void* fn, std::atomic<uint64_t>& done_mask, int bytes) {

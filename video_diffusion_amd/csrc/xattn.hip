@@ -162,7 +162,7 @@ __global__ __launch_bounds__(XC_WAVES * 64) void xattn_core_kernel(const XCoreAr
                 float mx = st[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx = xhalf_max(mx);
                 // some query's maximum grew (rare after the first tiles; wave-uniform branch): move m, rescale
                 const bool first = (t0 + tt == 0);
                 if (first || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(XC_WAVES * 64) void xattn_core_kernel(const XCoreAr
                 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, acc_frag(st, 1), o, 0, 0, 0);
             }
         }
-        lsum += __shfl_xor(lsum, 32);
+        lsum = xhalf_add(lsum);
         const float inv = 1.0f / lsum;                  // every query sees at least one real key (l >= 1)
         if (valid) {
             __bf16* op = a.o + grow * hid + head * 32 + half * 16;
