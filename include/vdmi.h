@@ -133,6 +133,11 @@ typedef struct vdmi_tapgemm_args {
     int32_t q_cols;                /* QKV_ATTN: leading output columns that are queries (scaled by
                                       q_scale); 0 = n/3 (q, k, v thirds), n = a query-only projection */
     int32_t act;                   /* PLAIN only: 0 = none, 1 = SiLU after the bias (before the residual) */
+    int32_t k_split;               /* PLAIN only, no act / residual: 0 or 1 = off; k = 2..4: the channel chunks are dealt
+                                      to k workgroups per tile (k times the workgroups of a small grid); share i writes
+                                      its partial sums to out + i * out_split_stride and the consumer adds them
+                                      (vdmi_rmsnorm_silu_sum); share 0 carries the bias */
+    int64_t out_split_stride;      /* elements between the partial outputs (multiple of 8)   */
 } vdmi_tapgemm_args;
 
 /* HOST. Tile the library will use for (epilogue, n): *bn = output-channel tile, *bkc = input
@@ -315,6 +320,11 @@ int vdmi_relpos_buckets(int n, int num_buckets, int max_distance, int32_t* out);
 int vdmi_rmsnorm_silu(const void* x, int ldx, void* out, int ldo, int64_t rows, int c, const float* gain,
                       int64_t gain_bstride, const float* shift, int64_t shift_bstride, int64_t rows_per_batch,
                       float norm_scale, const void* res, int ld_res, vdmi_stream stream);
+/* The same over the sum of `nparts` (1..4) partial inputs x + i * part_stride (elements): the partial outputs of a
+ * K-split vdmi_tapgemm are added in fp32 on the way in. */
+int vdmi_rmsnorm_silu_sum(const void* x, int nparts, int64_t part_stride, int ldx, void* out, int ldo, int64_t rows, int c,
+                          const float* gain, int64_t gain_bstride, const float* shift, int64_t shift_bstride,
+                          int64_t rows_per_batch, float norm_scale, const void* res, int ld_res, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * One DDPM ancestral step (vdp.py:939-952, 985-1002; coefficient gather = extract, vdp.py:835-838):

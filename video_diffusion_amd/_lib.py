@@ -52,6 +52,7 @@ class TapGemmArgs(C.Structure):
         ("out2", C.c_void_p),
         ("sla_hw", C.c_int32), ("tile_bn", C.c_int32),
         ("q_cols", C.c_int32), ("act", C.c_int32),
+        ("k_split", C.c_int32), ("out_split_stride", C.c_int64),
     ]
 
 
@@ -119,6 +120,9 @@ _SIGNATURES = {
     "vdmi_rmsnorm_silu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                     C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_int,
                                     C.c_void_p]),
+    "vdmi_rmsnorm_silu_sum": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p,
+                                        C.c_int, C.c_void_p]),
     "vdmi_ddpm_step_rng": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p, C.c_int,
                                      C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "vdmi_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs),

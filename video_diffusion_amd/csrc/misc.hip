@@ -601,19 +601,28 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const __bf16* __restr
                                                            const float* __restrict__ gain, long long gain_bstride,
                                                            const float* __restrict__ shift, long long shift_bstride,
                                                            long long rows_per_batch, float norm_scale,
-                                                           const __bf16* __restrict__ res, int ld_res) {
+                                                           const __bf16* __restrict__ res, int ld_res, int nparts,
+                                                           long long part_stride) {
     constexpr int RPB = 256 / LPR;
     const int sub = threadIdx.x % LPR;
     const long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
     const bool live = row < rows;
     const long long r = live ? row : rows - 1;
-    bf16x8 v[NV];
+    float v[NV][8];      // the row's values (the fp32 sum of the partial inputs when the producer split its contraction)
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        v[k] = *reinterpret_cast<const bf16x8*>(x + r * ldx + (k * LPR + sub) * 8);
+        const __bf16* src = x + r * ldx + (k * LPR + sub) * 8;
+        const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(src);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)v[k][e]; ss += f * f; }
+        for (int e = 0; e < 8; ++e) v[k][e] = (float)p0[e];
+        for (int p = 1; p < nparts; ++p) {
+            const bf16x8 pp = *reinterpret_cast<const bf16x8*>(src + p * part_stride);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] += (float)pp[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += v[k][e] * v[k][e];
     }
 #pragma unroll
     for (int m = 1; m < LPR; m <<= 1) ss += __shfl_xor(ss, m);
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const __bf16* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float g = e < 4 ? g0[e & 3] : g1[e & 3], sh = e < 4 ? s0[e & 3] : s1[e & 3];
-            o[e] = f2bf(silu_f(fmaf((float)v[k][e] * rinv, g, sh)) + (float)rv[e]);
+            o[e] = f2bf(silu_f(fmaf(v[k][e] * rinv, g, sh)) + (float)rv[e]);
         }
         if (live) *reinterpret_cast<bf16x8*>(out + r * ldo + ch) = o;
     }
@@ -856,11 +865,12 @@ extern "C" int vdmi_temporal_dwconv(const void* x, int ldx, void* out, int ldo, 
     return VDMI_OK;
 }
 
-extern "C" int vdmi_rmsnorm_silu(const void* x, int ldx, void* out, int ldo, int64_t rows, int c, const float* gain,
-                                 int64_t gain_bstride, const float* shift, int64_t shift_bstride,
-                                 int64_t rows_per_batch, float norm_scale, const void* res, int ld_res,
-                                 vdmi_stream stream_) {
-    if (!x || !out || !gain || rows <= 0 || rows_per_batch <= 0) return VDMI_E_ARG;
+extern "C" int vdmi_rmsnorm_silu_sum(const void* x, int nparts, int64_t part_stride, int ldx, void* out, int ldo, int64_t rows,
+                                     int c, const float* gain, int64_t gain_bstride, const float* shift,
+                                     int64_t shift_bstride, int64_t rows_per_batch, float norm_scale, const void* res,
+                                     int ld_res, vdmi_stream stream_) {
+    if (!x || !out || !gain || rows <= 0 || rows_per_batch <= 0 || nparts < 1 || nparts > 4) return VDMI_E_ARG;
+    if (nparts > 1 && (part_stride <= 0 || part_stride % 8)) return VDMI_E_ARG;
     if (c < 64 || c % 64 || ldx % 8 || ldo % 8 || (res && ld_res % 8) || gain_bstride % 4 || shift_bstride % 4)
         return VDMI_E_SHAPE;
     if (!aligned16(x) || !aligned16(out) || !aligned16(gain) || (shift && !aligned16(shift)) || (res && !aligned16(res)))
@@ -875,7 +885,8 @@ extern "C" int vdmi_rmsnorm_silu(const void* x, int ldx, void* out, int ldo, int
         if (blocks > 0x7fffffffLL) return VDMI_E_SHAPE;                                                     \
         hipLaunchKernelGGL((rmsnorm_silu_kernel<LPR_, NV_>), dim3((unsigned)blocks), dim3(256), 0, stream,  \
                            xp, ldx, op, ldo, (long long)rows, gain, (long long)gain_bstride, shift,         \
-                           (long long)shift_bstride, (long long)rows_per_batch, norm_scale, rp, ld_res);    \
+                           (long long)shift_bstride, (long long)rows_per_batch, norm_scale, rp, ld_res,     \
+                           nparts, (long long)part_stride);                                                 \
         VDMI_LAUNCH_CHECK();                                                                                \
         return VDMI_OK;                                                                                     \
     }
@@ -891,6 +902,14 @@ extern "C" int vdmi_rmsnorm_silu(const void* x, int ldx, void* out, int ldo, int
     VDMI_RMS_CASE(64, 3)    // 1536
 #undef VDMI_RMS_CASE
     return VDMI_E_SHAPE;
+}
+
+extern "C" int vdmi_rmsnorm_silu(const void* x, int ldx, void* out, int ldo, int64_t rows, int c, const float* gain,
+                                 int64_t gain_bstride, const float* shift, int64_t shift_bstride,
+                                 int64_t rows_per_batch, float norm_scale, const void* res, int ld_res,
+                                 vdmi_stream stream) {
+    return vdmi_rmsnorm_silu_sum(x, 1, 0, ldx, out, ldo, rows, c, gain, gain_bstride, shift, shift_bstride, rows_per_batch,
+                                 norm_scale, res, ld_res, stream);
 }
 
 extern "C" int vdmi_gather_scale_shift(const float* gain_table, const float* shift_table, int T, const int64_t* t, int b,

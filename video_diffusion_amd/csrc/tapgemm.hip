@@ -104,6 +104,8 @@ struct KArgs {
     int sla_hw;
     int heads32;
     int act;
+    int ksplit;
+    long long out_split_stride;
     unsigned long long* diag;
 };
 
@@ -116,7 +118,8 @@ template <int BM, int BN, int WM, int WN, int BKC, bool STATS, int WPD, class Pr
 __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32][WM / 32], __bf16* wbuf,
                                          __bf16* patch, float* stats, int frame, int ty, int tx, int ltw,
                                          int nt, int tid, float ln_eps, Pro&& after_first_loads,
-                                         unsigned long long* diag = nullptr, int phase = 0) {
+                                         unsigned long long* diag = nullptr, int phase = 0, int c_begin = 0,
+                                         int c_end = -1) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32, KS = BKC / 16, PROW = BKC + 8, PPR = BKC / 8;
     constexpr int WP = BN * BKC / 8 / NT;
@@ -162,7 +165,10 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
         for (int k = 0; k < KMAX; ++k) s1[k] = s2[k] = 0.f;
     }
 
-    const int nsteps = g.nch * ntp;
+    // this workgroup's share of the contraction: channel chunks [c_begin, c_end) (all of them unless K is split)
+    if (c_end < 0) c_end = g.nch;
+    wg += (long long)c_begin * ntp * g.wtile_all;
+    const int nsteps = (c_end - c_begin) * ntp;
     const int total = g.ph * g.pw * PPR;
     load_w(wreg[0], 0);
     if constexpr (DEEP) {
@@ -251,10 +257,10 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
                 if (r0 + u * RSTEP < nrows) *reinterpret_cast<bf16x8*>(patch + (r0 + u * RSTEP) * PROW + piece * 8) = pv[u];
         }
     };
-    patch_prefetch(0);
+    patch_prefetch(c_begin);
     after_first_loads();   // per-channel parameters, accumulator init: overlaps the loads above
 
-    int c = 0, t = 0;   // chunk and tap of the current step
+    int c = c_begin, t = 0;   // chunk and tap of the current step
     auto step = [&](int s, bf16x8 (&cur)[WP], bf16x8 (&nxt)[WP]) {
         if (t == 0) {
             __syncthreads();   // every wave is done with the previous chunk's patch
@@ -279,7 +285,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
                 }
             } else {
                 patch_commit();
-                if (c + 1 < g.nch) patch_prefetch(c + 1);
+                if (c + 1 < c_end) patch_prefetch(c + 1);
             }
         }
         __bf16* wb = wbuf + (s & 1) * BN * BKC;
@@ -381,8 +387,13 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
     const int h = lane >> 5;
     const int tile = blockIdx.x, ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int nph = a.main.phases > 1 ? a.main.phases : 1;
-    const int phase = blockIdx.z % nph;
-    const int nt = blockIdx.y, frame = (blockIdx.z / nph) * a.main.fstack, n0 = nt * BN;
+    // split K (PLAIN only): blockIdx.z also enumerates the `ksplit` shares of the channel chunks; share k writes its
+    // partial sums to out + k * out_split_stride (the consumer adds them), share 0 carries the bias
+    const int nks = a.ksplit > 1 ? a.ksplit : 1;
+    const int ksp = blockIdx.z % nks, zz = blockIdx.z / nks;
+    const int phase = zz % nph;
+    const int nt = blockIdx.y, frame = (zz / nph) * a.main.fstack, n0 = nt * BN;
+    const float* const bias_in = ksp == 0 ? a.bias : nullptr;
     const int ooy = a.out_off_y + phase / a.out_mul, oox = a.out_off_x + phase % a.out_mul;
     const int TW = 1 << a.ltw, TH = BM >> a.ltw;
     // output row of tile pixel p (-1: outside the image / past the last frame)
@@ -409,11 +420,11 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
             const bool ok = gc < a.n;
             if constexpr (EPI == VDMI_EPI_NORM_SILU) {
                 const int b = frame / a.frames_per_batch;
-                par[c] = (ok && a.bias) ? a.bias[gc] : 0.f;
+                par[c] = (ok && bias_in) ? bias_in[gc] : 0.f;
                 par[BN + c] = ok ? a.gain[b * a.gain_bstride + gc] : 0.f;
                 par[2 * BN + c] = (ok && a.shift) ? a.shift[b * a.shift_bstride + gc] : 0.f;
             } else if constexpr (EPI == VDMI_EPI_PLAIN) {
-                par[c] = (ok && a.bias) ? a.bias[gc] : 0.f;
+                par[c] = (ok && bias_in) ? bias_in[gc] : 0.f;
             } else {
                 par[c] = ok ? a.colsum[gc] : 0.f;
             }
@@ -427,7 +438,7 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (EPI == VDMI_EPI_NORM_SILU || EPI == VDMI_EPI_PLAIN) {
                     const int gc = n0 + (wn * MI + i) * 32 + 8 * rg + 4 * h;
-                    if (a.bias && gc < a.n) bv = *reinterpret_cast<const f32x4*>(a.bias + gc);
+                    if (bias_in && gc < a.n) bv = *reinterpret_cast<const f32x4*>(bias_in + gc);
                 }
     #pragma unroll
                 for (int j = 0; j < NJ; ++j)
@@ -440,7 +451,8 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
 
     constexpr bool STATS = (EPI == VDMI_EPI_QKV_ATTN || EPI == VDMI_EPI_QKV_SLA);
     VDMI_STAMP(a.diag, 0);
-    run_pass<BM, BN, WM, WN, BKC, STATS, WPD_MAIN>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag, phase);
+    run_pass<BM, BN, WM, WN, BKC, STATS, WPD_MAIN>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag, phase,
+                                                   ksp * a.main.nch / nks, (ksp + 1) * a.main.nch / nks);
     VDMI_STAMP(a.diag, 2);
     if constexpr (STATS) __syncthreads();   // row statistics written by the loader threads
 
@@ -664,7 +676,7 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
         const int row = k * RPI + srow0;
         const long long orw = staged_orow(row);
         const bf16x8 ov = *reinterpret_cast<const bf16x8*>(stg + row * SROW + schunk * 8);
-        if (orw >= 0 && chan_ok) *reinterpret_cast<bf16x8*>(a.out + orw * a.ldo + gcw) = ov;
+        if (orw >= 0 && chan_ok) *reinterpret_cast<bf16x8*>(a.out + ksp * a.out_split_stride + orw * a.ldo + gcw) = ov;
     }
     VDMI_STAMP(a.diag, 4);
 }
@@ -852,6 +864,9 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if ((long long)A.frames * A.main.in_h * A.main.in_w > (A.main.space_to_depth ? 0x7ffffffLL : 0x7fffffffLL))
         return VDMI_E_SHAPE;
     if (A.main.space_to_depth && (epi == VDMI_EPI_QKV_ATTN || epi == VDMI_EPI_QKV_SLA)) return VDMI_E_ARG;
+    if (A.k_split < 0 || A.k_split > 4) return VDMI_E_ARG;
+    if (A.k_split > 1 && (epi != VDMI_EPI_PLAIN || A.act || A.has_res || A.out_split_stride <= 0 || A.out_split_stride % 8))
+        return VDMI_E_ARG;
 
     // 64 -> 64 channel (1,3,3) convolutions of wide images: the weight-stationary kernel
     if (epi == VDMI_EPI_NORM_SILU) {
@@ -993,6 +1008,9 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         k.ln_eps = A.ln_eps;
         k.q_scale = A.q_scale;
         k.act = A.act;
+        k.ksplit = A.k_split > 1 ? A.k_split : 1;
+        k.out_split_stride = A.out_split_stride;
+        if (k.ksplit > k.main.nch) return VDMI_E_SHAPE;      // every share needs at least one channel chunk
         k.rot_cos = A.rot_cos;
         k.rot_sin = A.rot_sin;
         k.rot_frames = A.rot_frames > 0 ? A.rot_frames : 1;
@@ -1005,7 +1023,7 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
 #endif
         if (is_qkv && (k.heads32 % 32 || A.n % k.heads32)) return VDMI_E_SHAPE;
 
-        frames *= k.main.phases;    // grid.z: (frame group, phase)
+        frames *= k.main.phases * k.ksplit;    // grid.z: (frame group, phase, K share)
         if (best_tiles > 0x7fffffffLL || frames > 65535) return VDMI_E_SHAPE;
         const dim3 grid((unsigned)best_tiles, (unsigned)(npad / c.bn), (unsigned)frames);
         if (grid.y > 65535) return VDMI_E_SHAPE;

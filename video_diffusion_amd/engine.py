@@ -204,19 +204,31 @@ class Plan:
         (s0, c0), (s1, c1) = srcs[0], (srcs[1] if len(srcs) > 1 else (None, 0))
         w_pack, bias = pk
         n = w_pack.n
-        raw = self._buf(rows, n)
+        # Small images launch few workgroups (rows / 256 pixel tiles x n / 64 channel tiles) and each walks the whole
+        # contraction on its own: below ~one workgroup per CU the channel chunks are dealt to 2 or 4 workgroups per
+        # tile, which write partial sums that the normalisation kernel adds on its way in.  The choice is made for a
+        # nominal 8 samples per launch, not the actual batch: the order of a sample's additions must not depend on
+        # what else is in the batch (shards and sub-batches give the same bits).
+        wgs = max(1, (8 * self.F * h * w + 255) // 256) * (n // 64)
+        ksplit = 1
+        if K_SPLIT_BELOW and wgs < K_SPLIT_BELOW:
+            ksplit = min(4, max(1, 320 // wgs), (c0 + c1) // 64)
+            ksplit = 1 if ksplit < 2 else (2 if ksplit < 4 else 4)
+        raw = self._buf(ksplit * rows, n)
         a = self._base_args(frames, h, w, raw, n, EPI_PLAIN)
         _fill_pass(a.main, s0, c0, s1, c1, h, w, 1, TAPS_3x3, w_pack.data)
         a.bias = _ptr(bias)
         a.tile_bn = 64
+        if ksplit > 1:
+            a.k_split, a.out_split_stride = ksplit, rows * n
         self._tapgemm(a, name + ".conv")
         identity = res[1] if (res is not None and res[0] == "identity") else None
         if res is not None and res[0] == "identity" and len(res) > 2 and res[2]:
             self._join_next = True      # the residual was produced on the side stream
         out = self._buf(rows, n)
         meta = {"kernel": "rmsnorm_silu", "flops": 0.0, "bytes": 2.0 * rows * n * (3 if identity is not None else 2)}
-        self._add(lambda s, raw=raw, out=out, identity=identity: lib.vdmi_rmsnorm_silu(
-            raw.data_ptr(), n, out.data_ptr(), n, rows, n, _ptr(gain), bstride, _ptr(shift), bstride,
+        self._add(lambda s, raw=raw, out=out, identity=identity: lib.vdmi_rmsnorm_silu_sum(
+            raw.data_ptr(), ksplit, rows * n, n, out.data_ptr(), n, rows, n, _ptr(gain), bstride, _ptr(shift), bstride,
             self.F * h * w, float(n) ** 0.5, _ptr(identity), identity.shape[1] if identity is not None else 0, s),
             meta, name + ".norm")
         if res is not None and res[0] == "conv":
@@ -632,6 +644,8 @@ class Plan:
             main.wait_stream(self._side)
 
 
+# wide-layer convs that would launch fewer workgroups than this split their contraction (0: never)
+K_SPLIT_BELOW = int(os.environ.get("VDMI_K_SPLIT_BELOW", "256"))
 BATCH_PARTS = int(os.environ.get("VDMI_BATCH_PARTS", "2"))
 BATCH_PARTS_MIN = int(os.environ.get("VDMI_BATCH_PARTS_MIN", "4"))     # smallest batch that is split
 
