@@ -212,7 +212,7 @@ class Plan:
         wgs = max(1, (8 * self.F * h * w + 255) // 256) * (n // 64)
         ksplit = 1
         if K_SPLIT_BELOW and wgs < K_SPLIT_BELOW:
-            ksplit = min(4, max(1, 320 // wgs), (c0 + c1) // 64)
+            ksplit = min(4, max(1, K_SPLIT_TARGET // wgs), (c0 + c1) // 64)
             ksplit = 1 if ksplit < 2 else (2 if ksplit < 4 else 4)
         raw = self._buf(ksplit * rows, n)
         a = self._base_args(frames, h, w, raw, n, EPI_PLAIN)
@@ -646,6 +646,7 @@ class Plan:
 
 # wide-layer convs that would launch fewer workgroups than this split their contraction (0: never)
 K_SPLIT_BELOW = int(os.environ.get("VDMI_K_SPLIT_BELOW", "256"))
+K_SPLIT_TARGET = int(os.environ.get("VDMI_K_SPLIT_TARGET", "320"))      # workgroups per launch the split aims at
 BATCH_PARTS = int(os.environ.get("VDMI_BATCH_PARTS", "2"))
 BATCH_PARTS_MIN = int(os.environ.get("VDMI_BATCH_PARTS_MIN", "4"))     # smallest batch that is split
 
