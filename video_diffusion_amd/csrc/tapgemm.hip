@@ -48,6 +48,10 @@
 #ifndef VDMI_WPD_NORM
 #define VDMI_WPD_NORM 1
 #endif
+// the flat row GEMMs (1-tap passes, QKV projections): weight tiles AND row chunks this many steps ahead
+#ifndef VDMI_WPD_ROWS
+#define VDMI_WPD_ROWS 2
+#endif
 
 namespace {
 
@@ -114,7 +118,10 @@ constexpr int patch_lb(int bm, int nt) {
     return bm >= 256 ? (13 * 256 + nt - 1) / nt : (bm >= 64 ? (12 * 256 + nt - 1) / nt : 2);
 }
 
-template <int BM, int BN, int WM, int WN, int BKC, bool STATS, int WPD, class Pro>
+// ROWS: the pass is a flat row GEMM (one tap, tiles never leave a row range): the loader takes whole rows of a
+// channel chunk, and because every step is a new chunk it keeps a ring of them in flight (the same depth as the
+// weight ring), not just the next one.  STATS (the LayerNorm-folding QKV epilogues) implies ROWS.
+template <int BM, int BN, int WM, int WN, int BKC, bool STATS, bool ROWS, int WPD, class Pro>
 __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32][WM / 32], __bf16* wbuf,
                                          __bf16* patch, float* stats, int frame, int ty, int tx, int ltw,
                                          int nt, int tid, float ln_eps, Pro&& after_first_loads,
@@ -182,10 +189,29 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     constexpr int RSTEP = NT / PPR;
     static_assert(NT % PPR == 0, "row step must be whole");
     const int piece = tid % PPR, r0 = tid / PPR, nrows = g.ph * g.pw;
-    bf16x8 pv[STATS ? 1 : LB];
+    static_assert(ROWS || !STATS, "the statistics ride on the row loader");
+    bf16x8 pv[ROWS ? 1 : LB];
     // source pixel of each patch piece this thread stages (-1: padding) -- the same for every chunk
-    int ppix[STATS ? 1 : LB];
-    if constexpr (!STATS) {
+    int ppix[ROWS ? 1 : LB];
+    // ROWS: ring of row-chunk register sets, slot = step % RING (the step loop is unrolled by RING)
+    bf16x8 sv[ROWS ? RING : 1][KMAX];
+    auto rows_load = [&](int c, bf16x8 (&dst)[KMAX]) {
+        const __bf16* src;
+        int cs, cbase;
+        if (c < g.nch0) { src = g.src0; cs = g.c0; cbase = c * BKC; }
+        else            { src = g.src1; cs = g.c1; cbase = (c - g.nch0) * BKC; }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int idx = tid + k * NT;
+            const int r = idx / PPR, pc = idx % PPR;
+            const int ix = ix0 + r, ch = cbase + pc * 8;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (idx < total && ix < g.in_w && ch < cs)
+                v = *reinterpret_cast<const bf16x8*>(src + ((long long)frame * g.in_h * g.in_w + ix) * cs + ch);
+            dst[k] = v;
+        }
+    };
+    if constexpr (!ROWS) {
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
             // patch row -> (ry, rx): (r + 0.5) / pw is never within 0.5 / pw of an integer, far above fp32 rounding here
@@ -213,7 +239,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
         }
     }
     auto patch_prefetch = [&](int c) {
-        if constexpr (!STATS) {
+        if constexpr (!ROWS) {
             const __bf16* src;
             int cs, cbase;
             if (c < g.nch0) { src = g.src0; cs = g.c0; cbase = c * BKC; }
@@ -242,7 +268,7 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
         }
     };
     auto patch_commit = [&]() {
-        if constexpr (!STATS) {
+        if constexpr (!ROWS) {
             if (g.lskew) {
 #pragma unroll
                 for (int u = 0; u < LB; ++u) {
@@ -257,32 +283,34 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
                 if (r0 + u * RSTEP < nrows) *reinterpret_cast<bf16x8*>(patch + (r0 + u * RSTEP) * PROW + piece * 8) = pv[u];
         }
     };
-    patch_prefetch(c_begin);
+    if constexpr (ROWS) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) rows_load(min(c_begin + u, c_end - 1), sv[u]);
+    } else {
+        patch_prefetch(c_begin);
+    }
     after_first_loads();   // per-channel parameters, accumulator init: overlaps the loads above
 
     int c = c_begin, t = 0;   // chunk and tap of the current step
-    auto step = [&](int s, bf16x8 (&cur)[WP], bf16x8 (&nxt)[WP]) {
+    auto step = [&](int s, bf16x8 (&cur)[WP], bf16x8 (&nxt)[WP], bf16x8 (&rows)[KMAX]) {
         if (t == 0) {
             __syncthreads();   // every wave is done with the previous chunk's patch
-            if constexpr (STATS) {
-                const __bf16* src;
-                int cs, cbase;
-                if (c < g.nch0) { src = g.src0; cs = g.c0; cbase = c * BKC; }
-                else            { src = g.src1; cs = g.c1; cbase = (c - g.nch0) * BKC; }
+            if constexpr (ROWS) {
+                // this chunk's rows: registers -> LDS (+ LayerNorm sums), then the set is refilled RING chunks ahead
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k) {
                     const int idx = tid + k * NT;
                     if (idx < total) {
                         const int r = idx / PPR, pc = idx % PPR;
-                        const int ix = ix0 + r, ch = cbase + pc * 8;
-                        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (ix < g.in_w && ch < cs)
-                            v = *reinterpret_cast<const bf16x8*>(src + ((long long)frame * g.in_h * g.in_w + ix) * cs + ch);
+                        const bf16x8 v = rows[k];
                         *reinterpret_cast<bf16x8*>(patch + r * PROW + pc * 8) = v;
+                        if constexpr (STATS) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1[k] += f; s2[k] += f * f; }
+                            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1[k] += f; s2[k] += f * f; }
+                        }
                     }
                 }
+                rows_load(min(c + RING, c_end - 1), rows);
             } else {
                 patch_commit();
                 if (c + 1 < c_end) patch_prefetch(c + 1);
@@ -343,10 +371,10 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
         for (int s = 0; s < nsteps; s += RING) {
 #pragma unroll
             for (int u = 0; u < RING; ++u)
-                if (s + u < nsteps) step(s + u, wreg[u], wreg[(u + PD) % RING]);
+                if (s + u < nsteps) step(s + u, wreg[u], wreg[(u + PD) % RING], sv[ROWS ? u : 0]);
         }
     } else {
-        for (int s = 0; s < nsteps; ++s) step(s, wreg[0], wreg[0]);
+        for (int s = 0; s < nsteps; ++s) step(s, wreg[0], wreg[0], sv[0]);
     }
 
     if constexpr (STATS) {
@@ -369,13 +397,15 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BKC, int EPI>
+template <int BM, int BN, int WM, int WN, int BKC, int EPI, bool FLAT = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
 __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4 : 2))) void tapgemm_kernel(const KArgs a) {
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WN / 32, NJ = WM / 32;
     // deeper weight prefetch where the registers allow it: one 16-byte weight piece per thread and step
-    constexpr int WPD_MAIN = BN * BKC / 8 != NT ? 1 : EPI == VDMI_EPI_PLAIN ? VDMI_WPD : EPI == VDMI_EPI_NORM_SILU ? VDMI_WPD_NORM : 1;
+    constexpr bool STATS = (EPI == VDMI_EPI_QKV_ATTN || EPI == VDMI_EPI_QKV_SLA);
+    constexpr bool ROWS = STATS || FLAT;
+    constexpr int WPD_MAIN = ROWS ? VDMI_WPD_ROWS : BN * BKC / 8 != NT ? 1 : EPI == VDMI_EPI_PLAIN ? VDMI_WPD : EPI == VDMI_EPI_NORM_SILU ? VDMI_WPD_NORM : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* wbuf = reinterpret_cast<__bf16*>(smem);
     float* par = reinterpret_cast<float*>(smem + 2 * BN * BKC * 2);
@@ -383,6 +413,23 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
     float* stats = red + NWN * BM;
     __bf16* patch = reinterpret_cast<__bf16*>(stats + 2 * BM);
 
+    // The kernel arguments live in the kernarg segment and reach SGPRs by scalar loads.  Left alone the compiler
+    // loads each field where it is first needed, one dword at a time, and the tile set-up below becomes a chain of
+    // ~25 dependent load-wait pairs (several thousand cycles before the first global load is even issued).  Asking
+    // for the fields of the set-up in one place makes it issue them together (merged into wide loads) behind one wait:
+    // -2 900 cycles of 8 800 before the first barrier of a row GEMM.  Only there: in the convolution kernels the
+    // set-up is a small share of a workgroup's life and the extra live scalars cost more than they save.
+    if constexpr (STATS || FLAT) {
+    asm volatile("" ::"s"(a.tiles_x), "s"(a.ltw), "s"(a.grid_h), "s"(a.grid_w), "s"(a.ksplit), "s"(a.n), "s"(a.ldo),
+                 "s"(a.out_mul), "s"(a.out_h), "s"(a.out_w), "s"(a.frames_per_batch), "s"(a.has_res),
+                 "s"(a.main.phases), "s"(a.main.fstack), "s"(a.main.nframes), "s"(a.main.nch), "s"(a.main.nch0),
+                 "s"(a.main.c0), "s"(a.main.c1), "s"(a.main.in_h), "s"(a.main.in_w), "s"(a.main.stride),
+                 "s"(a.main.ntaps), "s"(a.main.min_dy), "s"(a.main.min_dx), "s"(a.main.ph), "s"(a.main.pw),
+                 "s"(a.main.lskew), "s"(a.main.s2d));
+    asm volatile("" ::"s"(a.main.src0), "s"(a.main.src1), "s"(a.main.w), "s"(a.main.wtile_all), "s"(a.main.w_group_stride),
+                 "s"(a.main.w_phase_stride), "s"(a.out), "s"(a.bias), "s"(a.out_split_stride), "s"(a.main.inv_pw),
+                 "s"(a.main.inv_phf), "s"(a.main.fs_rows), "s"(a.main.phf));
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave % NWM, wn = wave / NWM;
     const int h = lane >> 5;
     const int tile = blockIdx.x, ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -449,9 +496,8 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
 
     };
 
-    constexpr bool STATS = (EPI == VDMI_EPI_QKV_ATTN || EPI == VDMI_EPI_QKV_SLA);
     VDMI_STAMP(a.diag, 0);
-    run_pass<BM, BN, WM, WN, BKC, STATS, WPD_MAIN>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag, phase,
+    run_pass<BM, BN, WM, WN, BKC, STATS, ROWS, WPD_MAIN>(a.main, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, a.ln_eps, prologue, a.diag, phase,
                                                    ksp * a.main.nch / nks, (ksp + 1) * a.main.nch / nks);
     VDMI_STAMP(a.diag, 2);
     if constexpr (STATS) __syncthreads();   // row statistics written by the loader threads
@@ -509,7 +555,7 @@ __attribute__((amdgpu_waves_per_eu(((BM / WM) * (BN / WN) >= 8 && BM >= 128) ? 4
                     }
             }
         if (a.has_res == 1) {
-            run_pass<BM, BN, WM, WN, BKC, false, 1>(a.res, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, 0.f, [] {});
+            run_pass<BM, BN, WM, WN, BKC, false, false, 1>(a.res, acc, wbuf, patch, stats, frame, ty, tx, a.ltw, nt, tid, 0.f, [] {});
             if (a.res_bias) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -795,10 +841,10 @@ int patch_row_cap(const TileCfg& c) {
     return patch_lb(c.bm, nthreads) * nthreads / (c.bkc / 8);
 }
 
-template <int BM, int BN, int WM, int WN, int BKC, int EPI>
+template <int BM, int BN, int WM, int WN, int BKC, int EPI, bool FLAT = false>
 int launch(const KArgs& k, dim3 grid, size_t lds, hipStream_t stream) {
     static std::atomic<uint64_t> attr_mask{0};
-    auto fn = tapgemm_kernel<BM, BN, WM, WN, BKC, EPI>;
+    auto fn = tapgemm_kernel<BM, BN, WM, WN, BKC, EPI, FLAT>;
     if (vdmi_set_max_lds(reinterpret_cast<const void*>(fn), attr_mask, (int)kLdsMax)) return VDMI_E_LAUNCH;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     hipLaunchKernelGGL(fn, grid, dim3(NT), lds, stream, k);
@@ -1029,6 +1075,13 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
         if (grid.y > 65535) return VDMI_E_SHAPE;
         const size_t lds = lds_bytes(c, best_rows, best_ph * best_skew);
 
+        // plain row GEMMs (1 tap over flattened rows): the loader with the row-chunk ring
+        if (flat && epi == VDMI_EPI_PLAIN && k.main.fstack <= 1 && !k.main.s2d && k.main.phases <= 1) {
+            if (c.bm == 128 && c.bn == 128 && c.wm == 32 && c.wn == 64 && c.bkc == 64)
+                return launch<128, 128, 32, 64, 64, VDMI_EPI_PLAIN, true>(k, grid, lds, stream);
+            if (c.bm == 64 && c.bn == 128 && c.wm == 32 && c.wn == 64 && c.bkc == 64)
+                return launch<64, 128, 32, 64, 64, VDMI_EPI_PLAIN, true>(k, grid, lds, stream);
+        }
 #define VDMI_CASE(BM_, BN_, WM_, WN_, BKC_, EPI_)                                                   \
     if (c.bm == BM_ && c.bn == BN_ && c.wm == WM_ && c.wn == WN_ && c.bkc == BKC_ && epi == EPI_)  \
         return launch<BM_, BN_, WM_, WN_, BKC_, EPI_>(k, grid, lds, stream);
