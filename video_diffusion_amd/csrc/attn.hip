@@ -316,7 +316,9 @@ extern "C" int vdmi_attn_core(const void* qkv, void* out, int64_t rows, int head
     {   // keys / values staged in LDS when a useful number of groups fits
         const long long ngroups = rows / n_tok;
         const size_t row_bytes = (size_t)(2 * heads * 32 + 8) * 2;
-        int gpb = (512 / heads) / n_tok;      // about two passes of the 256 threads over (row, head) pairs
+        // one pass of the 256 threads over a workgroup's (row, head) pairs: each thread walks its keys serially, so
+        // the launch is as long as a thread's passes; more, smaller workgroups finish sooner (8x8 level: 86 -> 171)
+        int gpb = (256 / heads) / n_tok;
         if (gpb < 1) gpb = 1;
         const size_t lds = (size_t)gpb * n_tok * row_bytes;
         if (lds <= 150 * 1024) {
