@@ -368,7 +368,7 @@ extern "C" int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const
     const bool res = c <= 64 && lds_res <= 150 * 1024;
     const size_t lds = res ? lds_res : lds_dbuf;
     if (lds > 160 * 1024) return VDMI_E_LDS;
-    const int nwaves = res ? 12 : 8;
+    const int nwaves = res ? 12 : (c >= 256 ? 4 : 8);
     const int rounds = (a.ngroups + nwaves - 1) / nwaves;
     const int grid = rounds < 256 ? rounds : 256;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -388,6 +388,7 @@ extern "C" int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const
     VDMI_TATTN_CASE(32, false, 8)
     VDMI_TATTN_CASE(64, false, 8)
     VDMI_TATTN_CASE(128, false, 8)
+    VDMI_TATTN_CASE(256, false, 4)      // one wave per SIMD: the row and the output accumulators alone are 192 registers
 #undef VDMI_TATTN_CASE
 #undef VDMI_TATTN_CASE_
     return VDMI_E_SHAPE;

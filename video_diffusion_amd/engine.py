@@ -344,7 +344,10 @@ class Plan:
         frames, hw = self.B * self.F, h * w
         rows = frames * hw
         hid = at["hid"]
-        if temporal and at.get("fused") is not None and self.F <= 32:
+        # the 256-channel form of the fused kernel runs one wave per SIMD and streams 64 KB of weights per head: it
+        # pays on 16x16 images (34 us against 58 for the three launches at 8 samples), not on 8x8 (33 against 30).
+        # Decided by the image, never by the batch, so a sample's bits do not depend on the batch.
+        if temporal and at.get("fused") is not None and self.F <= 32 and (c < 256 or hw >= 256):
             y = self._buf(rows, c)
             wp = at["fused"]
             meta = {"kernel": "tattn_fused", "flops": 2.0 * rows * c * 4 * hid + 4.0 * rows * self.F * hid,
@@ -644,6 +647,8 @@ class Plan:
             main.wait_stream(self._side)
 
 
+# channel widths whose temporal attention runs as the one fused kernel (VDMI_TATTN_256=0: 256 stays on the three-launch path)
+FUSED_TATTN_CHANNELS = (32, 64, 128) + ((256,) if os.environ.get("VDMI_TATTN_256", "1") != "0" else ())
 # wide-layer convs that would launch fewer workgroups than this split their contraction (0: never)
 K_SPLIT_BELOW = int(os.environ.get("VDMI_K_SPLIT_BELOW", "256"))
 K_SPLIT_TARGET = int(os.environ.get("VDMI_K_SPLIT_TARGET", "320"))      # workgroups per launch the split aims at
@@ -836,7 +841,7 @@ class UnetEngine:
                     idx[base:base + dh] = base + perm
             wq = wq[idx]
         fused = None
-        if cdim in (32, 64, 128) and att.rotary_emb is not None:
+        if cdim in FUSED_TATTN_CHANNELS and att.rotary_emb is not None:
             lib = _lib.lib()
             buf = torch.empty(lib.vdmi_pack_tattn_elems(cdim, hid // 32), dtype=torch.int16)
             wo = att.to_out.weight.detach().float().cpu().contiguous()
