@@ -204,6 +204,10 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
             // ---- projections ----------------------------------------------------------------------
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 q = zero, k = zero, v = zero;
+            // long contractions: v is not needed until the scores are done, so the scheduler sinks its products below
+            // the rotary of q and k, where they would run as one chain of dependent MFMAs; two accumulators (even / odd
+            // k-steps) keep neighbouring MFMAs independent wherever they end up
+            [[maybe_unused]] f32x16 v1 = zero;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 wq = *reinterpret_cast<const bf16x8*>(wfrag + (0 * KS + ks) * 512);
@@ -211,7 +215,12 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
                 const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wfrag + (2 * KS + ks) * 512);
                 q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq, xh[ks], q, 0, 0, 0);
                 k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk, xh[ks], k, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[ks], wv, v, 0, 0, 0);
+                if (C >= 256 && (ks & 1)) v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[ks], wv, v1, 0, 0, 0);
+                else v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[ks], wv, v, 0, 0, 0);
+            }
+            if constexpr (C >= 256) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += v1[r];
             }
             // q scale (times log2 e) + half-split rotary (feature d pairs with d+16 = register r with r+8)
 #pragma unroll

@@ -64,6 +64,9 @@ class PackedTaps:
 SPLIT_MIN_CHANNELS = int(os.environ.get("VDMI_SPLIT_MIN_CHANNELS", "256"))
 TIME_TABLES = os.environ.get("VDMI_TIME_TABLES", "1") != "0"          # sampling loops copy scale/shift rows from per-timestep tables
 SIDE_RES_CONV = os.environ.get("VDMI_SIDE_RES_CONV", "1") != "0"      # res_conv GEMMs of the wide layers on the side stream
+# ... and of the 64-channel blocks the weight-stationary conv covers (their block2 then has an identity residual).  Off:
+# measured 4.06 -> 4.15 ms per step; the extra 1x1 GEMM moves 126 MB more per layer than the fused second pass it replaces
+SIDE_RES_WS = os.environ.get("VDMI_SIDE_RES_WS", "0") != "0"
 
 TAPS_3x3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 TAPS_4x4_S2 = [(ky - 1, kx - 1) for ky in range(4) for kx in range(4)]
@@ -188,7 +191,9 @@ class Plan:
                 _fill_pass(a.res, r0, rc0, r1, rc1, h, w, 1, [(0, 0)], rpack.data)
                 a.res_bias = _ptr(rbias)
             else:
-                _, rt = res
+                rt = res[1]
+                if len(res) > 2 and res[2]:
+                    self._join_next = True      # the residual was produced on the side stream
                 a.has_res = 2
                 a.res_identity, a.ld_res = _ptr(rt), rt.shape[1]
         self._tapgemm(a, name)
@@ -255,9 +260,12 @@ class Plan:
         else:
             g1, s1, bstride = rb["gamma1"], None, 0
         early = None
-        if SIDE_RES_CONV and rb["wres"] is not None and "wt" not in rb and rb["w2"].tile_bn == 64:
-            # wide layers: res_conv(x) is its own 1x1 GEMM.  It depends on the block's input only, so it runs on the
-            # side stream beside block1 / block2 and comes back as the residual of block2's normalisation kernel.
+        # 64 -> 64 channel block2 of a 32- or 64-pixel-wide image: with an identity residual it runs on the
+        # weight-stationary kernel, which has no fused 1x1 pass
+        ws_block2 = (SIDE_RES_WS and rb["w2"].n == 64 and rb["w1"].n == 64 and w in (32, 64) and h % (256 // w) == 0)
+        if SIDE_RES_CONV and rb["wres"] is not None and "wt" not in rb and (rb["w2"].tile_bn == 64 or ws_block2):
+            # res_conv(x) is its own 1x1 GEMM.  It depends on the block's input only, so it runs on the side stream
+            # beside block1 / block2 and comes back as the residual of block2 (wide layers: of its normalisation kernel).
             if self._tables_pending:
                 self._tables_pending = False
                 self._join_next = True
