@@ -352,6 +352,19 @@ int vdmi_ddpm_step(const float* x, const float* eps, const float* z, const int64
 int vdmi_ddpm_step_rng(const float* x, const float* eps, const int64_t* t, const vdmi_ddpm_coefs* coefs,
                        float* out, int b, int64_t per_sample, int clip, const uint64_t* rng_state, vdmi_stream stream);
 
+/* Dynamic thresholding of the predicted x0 (vdp.py:957-968, 987-997; use_dynamic_thres of GaussianDiffusion):
+ *   thres[i] = max(1, torch.quantile(|x0_i|, percentile))   over the per_sample elements of sample i,
+ * x0 = srac[t]*x - srmac[t]*eps as in vdmi_ddpm_step, the quantile with torch's linear interpolation between the
+ * order statistics of ranks floor / ceil of percentile * (per_sample - 1) (float32 rank arithmetic, per_sample < 2^24).
+ * The order statistics are exact (radix select over the float bit patterns).  thres: float [b]. */
+int vdmi_dynamic_threshold(const float* x, const float* eps, const int64_t* t, const vdmi_ddpm_coefs* coefs,
+                           float* thres, int b, int64_t per_sample, float percentile, vdmi_stream stream);
+/* vdmi_ddpm_step / vdmi_ddpm_step_rng with x0 = clamp(x0, -thres[i], thres[i]) / thres[i] in place of the clip to
+ * [-1, 1] (vdp.py:966-968).  Exactly one of z (float32 noise) and rng_state (see vdmi_ddpm_step_rng) is non-NULL. */
+int vdmi_ddpm_step_thres(const float* x, const float* eps, const float* z, const int64_t* t,
+                         const vdmi_ddpm_coefs* coefs, const float* thres, float* out, int b, int64_t per_sample,
+                         const uint64_t* rng_state, vdmi_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

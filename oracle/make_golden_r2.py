@@ -10,6 +10,8 @@
 * cfg3_branches  : config[3] model: the conditional and the null-conditioned epsilon separately
   (the two evaluations inside forward_with_cond_scale, video_diffusion_pytorch.py:731-748).
 * cfg4_eps       : the training-config shape, Unet3D(dim 128, channels 3) on (1, 3, 16, 128, 128), one epsilon.
+* p_sample_step_dyn_T250 : one p_sample step with use_dynamic_thres=True (known epsilon, injected noise) and the
+  per-sample thresholds.
 * cfg1_embed     : the B = 2 inputs / outputs of cfg1_eps need no new data; nothing is written for it.
 Fixtures hold inputs' keys and the reference's outputs only; weights come from oracle.weightgen.
 """
@@ -110,6 +112,34 @@ def main(which):
         save("cfg4_eps", t=t4, eps=eps.to(torch.float16))       # half precision halves the fixture; the bar is 2e-2
         del m4
 
+    if "dyn" in which:
+        # one p_sample step of the reference with dynamic thresholding (video_diffusion_pytorch.py:973-1002 with
+        # use_dynamic_thres=True), known epsilon and injected noise; the timesteps make the 0.9-quantile of |x0| fall
+        # below 1 (clamped to 1) in some samples and far above it in others
+        Fr, H = 4, 12
+        shape = (4, 3, Fr, H, H)
+        gd = vdp.GaussianDiffusion(torch.nn.Identity(), torch.nn.Identity(), image_size=H, num_frames=Fr, channels=3,
+                                   timesteps=250, use_dynamic_thres=True, dynamic_thres_percentile=0.9)
+        xs, es, zs = inp("dyn.x", shape, scale=1.2), inp("dyn.eps", shape), inp("dyn.z", shape)
+        xs[0] *= 0.25                                        # sample 0: quantile below 1, the threshold clamps to 1
+        ts = torch.tensor([0, 3, 60, 249])
+
+        class _Fixed(torch.nn.Module):
+            def forward(self, x, t, **k):
+                return es
+
+        gd.denoise_fn = _Fixed()
+        real_randn_like = torch.randn_like
+        torch.randn_like = lambda x, **k: zs.clone()
+        try:
+            out = gd.p_sample(xs, ts)
+        finally:
+            torch.randn_like = real_randn_like
+        x0 = gd.predict_start_from_noise(xs, t=ts, noise=es)
+        s = torch.quantile(x0.reshape(4, -1).abs(), 0.9, dim=-1).clamp(min=1.)
+        print("dyn thresholds", s.tolist())
+        save("p_sample_step_dyn_T250", t=ts, out=out, s=s)
+
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["cfg0", "cfg3", "cfg4"])
+    main(sys.argv[1:] or ["cfg0", "cfg3", "cfg4", "dyn"])

@@ -130,6 +130,38 @@ def test_graph_replay_equals_eager_loop_with_philox():
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_dynamic_threshold_loop_graph_equals_eager_and_torch_expressions():
+    """use_dynamic_thres=True: the captured loop (selection kernel + thresholded step inside the graph) equals the eager
+    loop bit for bit, and, with injected noise, the loop whose posterior is the reference's torch expressions
+    (torch.quantile, clamp, divide: vdp.py:957-968) on the same epsilons to float32 rounding."""
+    gd = _tiny_gd()
+    gd.use_dynamic_thres, gd.dynamic_thres_percentile = True, 0.9
+    shape = (2, 3, 4, 12, 12)
+    x_T = inp("dynloop.xT", shape) * 1.5
+    torch.manual_seed(9)
+    gd.use_hip_graph = True
+    a = gd.p_sample_loop(shape, x_T=x_T)
+    assert gd._graphs, "the loop did not go through a captured graph"
+    torch.manual_seed(9)
+    gd.use_hip_graph = False
+    b = gd.p_sample_loop(shape, x_T=x_T)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    # injected noise: fused step against p_mean_variance's torch expressions, step by step on the same state
+    T = gd.num_timesteps
+    img = x_T.to(a.device)
+    worst = 0.0
+    for k, i in enumerate(reversed(range(T - 3, T))):
+        t = torch.full((shape[0],), i, device=a.device, dtype=torch.long)
+        z = inp(f"dynloop.z{k}", shape).to(a.device)
+        with torch.no_grad():
+            mean, _, logvar = gd.p_mean_variance(img, t, clip_denoised=True)
+            want = mean + (0.5 * logvar).exp() * z
+        got = gd.p_sample(img, t, noise=z)
+        worst = max(worst, float((got - want).abs().max() / want.abs().max()))
+        img = got
+    assert record("dyn_thres_loop_vs_torch", worst, 1e-5) < 1e-5
+
+
 def test_philox_noise_differs_between_calls():
     """Two loops of the same shape on one object (the second replays the cached graph) draw different noise; the same
     torch seed reproduces a loop."""

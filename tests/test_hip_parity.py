@@ -690,6 +690,53 @@ def test_ddpm_step_matches_reference():
             assert torch.equal(gd2.state_dict()[k], v), k
 
 
+def test_dynamic_threshold_step_matches_reference():
+    """use_dynamic_thres=True (reference vdp.py:957-968, 987-997): the selection kernel's per-sample thresholds and the
+    thresholded step against one p_sample of the reference with known epsilon and injected noise."""
+    import ctypes as C
+    from video_diffusion_amd import GaussianDiffusion, _lib
+    g = golden("p_sample_step_dyn_T250")
+    shape = (4, 3, 4, 12, 12)
+    x, e, z = inp("dyn.x", shape, scale=1.2), inp("dyn.eps", shape), inp("dyn.z", shape)
+    x[0] *= 0.25
+    gd = GaussianDiffusion(torch.nn.Identity(), torch.nn.Identity(), image_size=12, num_frames=4, timesteps=250,
+                           use_dynamic_thres=True, dynamic_thres_percentile=0.9).to(dev())
+    xd, ed, t = x.to(dev()), e.to(dev()), g["t"].to(dev())
+    s = torch.empty(4, device=dev())
+    st = _lib.lib().vdmi_dynamic_threshold(xd.data_ptr(), ed.data_ptr(), t.data_ptr(), C.byref(gd._coefs()), s.data_ptr(), 4,
+                                           x.numel() // 4, 0.9, torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert float(s[0]) == 1.0
+    assert record("dyn_thres_s", float(((s.cpu() - g["s"]).abs() / g["s"]).max()), 1e-6) < 1e-6
+    out = gd.ddpm_step(xd, ed, t, noise=z.to(dev()))
+    torch.cuda.synchronize()
+    assert record("dyn_thres_step", rel_err(out.cpu(), g["out"]), 1e-6) < 1e-6
+
+
+@pytest.mark.parametrize("n,q", [(40960, 0.9), (40960, 0.995), (1000, 0.5), (7, 0.9), (1, 0.9), (786432, 0.9), (4097, 1.0), (4097, 0.0)])
+def test_dynamic_threshold_is_torch_quantile(n, q):
+    """Exact order statistics, torch's interpolation: the kernel's threshold equals max(1, torch.quantile(|x0|, q)) of the
+    same x0 to the last bit or two (x0 itself is one fused multiply-add here, two roundings in torch), ties included."""
+    import ctypes as C
+    from video_diffusion_amd import GaussianDiffusion, _lib
+    gd = GaussianDiffusion(torch.nn.Identity(), torch.nn.Identity(), image_size=8, num_frames=2, timesteps=100).to(dev())
+    gen = torch.Generator().manual_seed(n + int(q * 1000))
+    b = 3
+    x = (torch.randn(b, n, generator=gen) * 3).to(dev())
+    e = torch.zeros(b, n, device=dev())                   # eps = 0: x0 = srac[t] * x exactly in both
+    x[1] = (x[1] * 2).round() / 2                        # heavy ties in sample 1
+    t = torch.tensor([0, 10, 99], device=dev())
+    s = torch.empty(b, device=dev())
+    st = _lib.lib().vdmi_dynamic_threshold(x.data_ptr(), e.data_ptr(), t.data_ptr(), C.byref(gd._coefs()), s.data_ptr(), b, n,
+                                           q, torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    x0 = gd.sqrt_recip_alphas_cumprod[t].view(b, 1) * x
+    ref = torch.quantile(x0.abs(), q, dim=-1).clamp(min=1.)
+    assert torch.allclose(s, ref, rtol=3e-7, atol=0), (s.tolist(), ref.tolist())
+
+
 def test_ddpm_step_philox_statistics():
     """In-kernel noise: unit variance, zero mean, no noise at t == 0, fresh noise per timestep."""
     from video_diffusion_amd import GaussianDiffusion

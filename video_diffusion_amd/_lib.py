@@ -127,6 +127,10 @@ _SIGNATURES = {
                                      C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "vdmi_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs),
                                  C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "vdmi_dynamic_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p, C.c_int,
+                                         C.c_int64, C.c_float, C.c_void_p]),
+    "vdmi_ddpm_step_thres": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

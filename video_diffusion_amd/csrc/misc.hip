@@ -386,11 +386,96 @@ __device__ __forceinline__ void normal4(uint64_t group, uint64_t seed, float (&z
     }
 }
 
+// predicted x_0 of one element (vdp.py:939-943); the threshold kernel and the step kernel must agree on it bit for bit
+__device__ __forceinline__ float x0_of(float a, float x, float bb, float e) { return a * x - bb * e; }
+
+// ------------------------------------------------------------------------------------------
+// Dynamic thresholding (vdp.py:957-968, 987-997): s = max(1, quantile(|x_0|, q)) per sample, with torch.quantile's
+// linear interpolation between the two order statistics around rank q * (n - 1).  One workgroup per sample: the
+// order statistic is found exactly by a radix select over the bit patterns of |x_0| (non-negative floats order like
+// unsigned integers), four passes of a 256-bin histogram from the top byte down, and a fifth pass finds the next
+// larger value when the interpolation needs it.  x_0 is recomputed from x and eps on every pass (n is small: one
+// sample's elements; the passes hit L2).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dynamic_threshold_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                                 const int64_t* __restrict__ t, vdmi_ddpm_coefs cf,
+                                                                 float* __restrict__ thres, long long n, float q) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel[4];      // chosen bin, remaining rank, count <= value, smallest larger pattern
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int64_t tb = t[b];
+    const float a = cf.sqrt_recip_alphas_cumprod[tb], bb = cf.sqrt_recipm1_alphas_cumprod[tb];
+    const float* xs = x + (long long)b * n;
+    const float* es = eps + (long long)b * n;
+    // ranks as torch.quantile computes them for float32 input
+    const float pos = q * (float)(n - 1);
+    const float lo_f = floorf(pos), wgt = pos - lo_f;
+    const bool two = ceilf(pos) != lo_f;
+    unsigned k = (unsigned)lo_f, prefix = 0, mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (long long i = tid; i < n; i += 1024) {
+            const unsigned u = __float_as_uint(fabsf(x0_of(a, xs[i], bb, es[i])));
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane l owns bins 4l .. 4l+3; inclusive scan of the lane sums, then the lane holding rank k picks its bin
+            unsigned c[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c[j] = hist[4 * tid + j]; sum += c[j]; }
+            unsigned incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned up = __shfl_up(incl, d);
+                if (tid >= d) incl += up;
+            }
+            unsigned below = incl - sum;
+            if (k >= below && k < incl) {
+                int j = 0;
+                while (j < 3 && k >= below + c[j]) { below += c[j]; ++j; }
+                sel[0] = 4u * tid + j;
+                sel[1] = k - below;
+                sel[2] = c[j];
+            }
+        }
+        __syncthreads();
+        prefix |= sel[0] << shift;
+        mask |= 255u << shift;
+        k = sel[1];
+        __syncthreads();
+    }
+    // prefix is the pattern of the order statistic of rank floor(pos); k its rank among the sel[2] equal values
+    const float v_lo = __uint_as_float(prefix);
+    float v_hi = v_lo;
+    if (two && k + 1 >= sel[2]) {      // the next rank is the smallest value above
+        if (tid == 0) sel[3] = 0xffffffffu;
+        __syncthreads();
+        unsigned m = 0xffffffffu;
+        for (long long i = tid; i < n; i += 1024) {
+            const unsigned u = __float_as_uint(fabsf(x0_of(a, xs[i], bb, es[i])));
+            if (u > prefix && u < m) m = u;
+        }
+        atomicMin(&sel[3], m);
+        __syncthreads();
+        if (sel[3] != 0xffffffffu) v_hi = __uint_as_float(sel[3]);
+    }
+    if (tid == 0) {
+        // torch's lerp
+        const float d = v_hi - v_lo;
+        const float s = wgt < 0.5f ? v_lo + wgt * d : v_hi - d * (1.0f - wgt);
+        thres[b] = fmaxf(s, 1.0f);
+    }
+}
+
 __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                                         const float* __restrict__ z, const int64_t* __restrict__ t,
                                                         vdmi_ddpm_coefs cf, float* __restrict__ out, long long per_sample,
                                                         long long groups_per_sample, int clip, uint64_t seed,
-                                                        uint64_t offset, const uint64_t* __restrict__ rng) {
+                                                        uint64_t offset, const uint64_t* __restrict__ rng,
+                                                        const float* __restrict__ thres) {
     // rng != null: key and counter offset live in device memory (a captured graph then draws what the buffer says)
     if (rng) { seed = rng[0]; offset = rng[1]; }
     const int b = blockIdx.y;
@@ -399,6 +484,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
     const float c1 = cf.posterior_mean_coef1[tb], c2 = cf.posterior_mean_coef2[tb];
     const float sigma = tb != 0 ? expf(0.5f * cf.posterior_log_variance_clipped[tb]) : 0.f;
     const long long base = (long long)b * per_sample;
+    const float thr = thres ? thres[b] : 1.0f;      // dynamic thresholding: clamp to +-thres[b], then divide by it
     for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups_per_sample; g += (long long)gridDim.x * 256) {
         const long long i0 = g * 4;
         const int cnt = (int)((per_sample - i0) < 4 ? (per_sample - i0) : 4);
@@ -428,8 +514,9 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
         float ov[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x0 = a * xv[e] - bb * ev[e];
-            if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            float x0 = x0_of(a, xv[e], bb, ev[e]);
+            if (thres) x0 = fminf(fmaxf(x0, -thr), thr) / thr;
+            else if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
             ov[e] = c1 * x0 + c2 * xv[e] + sigma * zv[e];
         }
         if (cnt == 4 && (per_sample & 3) == 0) {
@@ -542,7 +629,8 @@ extern "C" int vdmi_block_scale_shift(const float* emb_silu, int b, int emb_dim,
 
 static int ddpm_step_launch(const float* x, const float* eps, const float* z, const int64_t* t,
                             const vdmi_ddpm_coefs* coefs, float* out, int b, int64_t per_sample, int clip,
-                            uint64_t seed, uint64_t offset, const uint64_t* rng, vdmi_stream stream) {
+                            uint64_t seed, uint64_t offset, const uint64_t* rng, vdmi_stream stream,
+                            const float* thres = nullptr) {
     if (!x || !eps || !t || !coefs || !out) return VDMI_E_ARG;
     if (!coefs->sqrt_recip_alphas_cumprod || !coefs->sqrt_recipm1_alphas_cumprod || !coefs->posterior_mean_coef1 ||
         !coefs->posterior_mean_coef2 || !coefs->posterior_log_variance_clipped)
@@ -555,7 +643,7 @@ static int ddpm_step_launch(const float* x, const float* eps, const float* z, co
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)bx, (unsigned)b), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, eps, z, t, *coefs, out, (long long)per_sample, groups, clip,
-                       seed, offset, rng);
+                       seed, offset, rng, thres);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
@@ -571,6 +659,26 @@ extern "C" int vdmi_ddpm_step_rng(const float* x, const float* eps, const int64_
                                   vdmi_stream stream) {
     if (!rng_state || (reinterpret_cast<uintptr_t>(rng_state) & 7u)) return VDMI_E_ARG;
     return ddpm_step_launch(x, eps, nullptr, t, coefs, out, b, per_sample, clip, 0, 0, rng_state, stream);
+}
+
+extern "C" int vdmi_dynamic_threshold(const float* x, const float* eps, const int64_t* t, const vdmi_ddpm_coefs* coefs,
+                                      float* thres, int b, int64_t per_sample, float percentile, vdmi_stream stream) {
+    if (!x || !eps || !t || !coefs || !thres) return VDMI_E_ARG;
+    if (!coefs->sqrt_recip_alphas_cumprod || !coefs->sqrt_recipm1_alphas_cumprod) return VDMI_E_ARG;
+    if (b <= 0 || b > 65535 || per_sample <= 0 || per_sample >= (1LL << 24)) return VDMI_E_SHAPE;   // ranks are float32, as in torch
+    if (!(percentile >= 0.f && percentile <= 1.f)) return VDMI_E_ARG;
+    hipLaunchKernelGGL(dynamic_threshold_kernel, dim3((unsigned)b), dim3(1024), 0, static_cast<hipStream_t>(stream), x, eps,
+                       t, *coefs, thres, (long long)per_sample, percentile);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_ddpm_step_thres(const float* x, const float* eps, const float* z, const int64_t* t,
+                                    const vdmi_ddpm_coefs* coefs, const float* thres, float* out, int b,
+                                    int64_t per_sample, const uint64_t* rng_state, vdmi_stream stream) {
+    if (!thres || (z == nullptr) == (rng_state == nullptr)) return VDMI_E_ARG;      // exactly one noise source
+    if (rng_state && (reinterpret_cast<uintptr_t>(rng_state) & 7u)) return VDMI_E_ARG;
+    return ddpm_step_launch(x, eps, z, t, coefs, out, b, per_sample, 1, 0, 0, rng_state, stream, thres);
 }
 
 // ------------------------------------------------------------------------------------------

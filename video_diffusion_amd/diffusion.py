@@ -167,6 +167,21 @@ class GaussianDiffusion(nn.Module):
         eps = eps.to(torch.float32).contiguous()
         out = torch.empty_like(x) if out is None else out
         b = x.shape[0]
+        if clip_denoised and self.use_dynamic_thres:
+            # per-sample quantile threshold (reference vdp.py:957-968): one selection kernel, then the step kernel
+            # clamps to +-s and divides by s
+            lib, stream = _lib.lib(), torch.cuda.current_stream().cuda_stream
+            thres = torch.empty(b, device=x.device, dtype=torch.float32)
+            check(lib.vdmi_dynamic_threshold(x.data_ptr(), eps.data_ptr(), t.data_ptr(), C.byref(self._coefs()),
+                                             thres.data_ptr(), b, x.numel() // b, float(self.dynamic_thres_percentile),
+                                             stream), "vdmi_dynamic_threshold")
+            if noise is None and rng_state is None:      # a key of its own for this call
+                rng_state = torch.tensor([seed, offset], device=x.device, dtype=torch.int64)
+            check(lib.vdmi_ddpm_step_thres(
+                x.data_ptr(), eps.data_ptr(), None if noise is None else noise.contiguous().data_ptr(), t.data_ptr(),
+                C.byref(self._coefs()), thres.data_ptr(), out.data_ptr(), b, x.numel() // b,
+                None if noise is not None else rng_state.data_ptr(), stream), "vdmi_ddpm_step_thres")
+            return out
         if noise is None and rng_state is not None:
             check(_lib.lib().vdmi_ddpm_step_rng(
                 x.data_ptr(), eps.data_ptr(), t.data_ptr(), C.byref(self._coefs()), out.data_ptr(), b, x.numel() // b,
@@ -188,13 +203,6 @@ class GaussianDiffusion(nn.Module):
         # reference: vdp.py:973-1002.  rng_state: with noise_source "philox", the device words a sampling loop keyed
         # its noise with (None: a fresh key per call)
         predicted_noise = self._predict_noise(x, t, frame_cond_features)
-        if clip_denoised and self.use_dynamic_thres:
-            # per-sample quantile threshold (off by default): elementwise torch expressions
-            x_recon = self._dynamic_clip(self.predict_start_from_noise(x, t=t, noise=predicted_noise))
-            model_mean, _, model_log_variance = self.q_posterior(x_start=x_recon, x_t=x, t=t)
-            noise = torch.randn_like(x) if noise is None else noise
-            nonzero_mask = (1 - (t == 0).float()).reshape(x.shape[0], *((1,) * (len(x.shape) - 1)))
-            return model_mean + nonzero_mask * (0.5 * model_log_variance).exp() * noise
         if noise is None and self.noise_source == "torch":
             noise = torch.randn_like(x)
         seed = 0 if (noise is not None or rng_state is not None) else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
@@ -206,11 +214,12 @@ class GaussianDiffusion(nn.Module):
         """One denoise step (Unet3D plan + posterior kernel) captured in a HIP graph."""
         from .modules import Unet3D
         fn = self.denoise_fn
-        if not (self.use_hip_graph and isinstance(fn, Unet3D) and not fn.has_cond and not self.use_dynamic_thres):
+        if not (self.use_hip_graph and isinstance(fn, Unet3D) and not fn.has_cond):
             return None
         fn.engine().ensure_packed(device, check_values=True)
         pack_id = fn.engine().pack_id
-        key = (tuple(shape), str(device), self.noise_source, pack_id)
+        key = (tuple(shape), str(device), self.noise_source, pack_id, bool(self.use_dynamic_thres),
+               float(self.dynamic_thres_percentile))
         if key in self._graphs:
             return self._graphs[key]
         for old in [k for k in self._graphs if k[0] != "cond" and k[3] != pack_id]:      # graphs over weights repacked since
@@ -258,7 +267,7 @@ class GaussianDiffusion(nn.Module):
             self.denoise_fn.engine().ensure_packed(device, check_values=True)
         runner = self._graph_runner(shape, device) if noises is None else None
         rng = None
-        if noises is None and self.noise_source == "philox" and not self.use_dynamic_thres:
+        if noises is None and self.noise_source == "philox":
             self.reseed_noise(device)           # one key per loop; graph replay and the eager loop draw the same field
             rng = self._rng_state(device)
         if runner is not None:
@@ -279,7 +288,8 @@ class GaussianDiffusion(nn.Module):
         fn = self.denoise_fn
         eng = fn.engine()
         eng.ensure_packed(device, check_values=True)
-        key = ("cond", tuple(shape), rep, str(device), self.noise_source, eng.pack_id, bool(self.use_hip_graph))
+        key = ("cond", tuple(shape), rep, str(device), self.noise_source, eng.pack_id, bool(self.use_hip_graph),
+               bool(self.use_dynamic_thres), float(self.dynamic_thres_percentile))
         if key in self._graphs:
             return self._graphs[key]
         for old in [k for k in self._graphs if k[0] == "cond" and k[5] != eng.pack_id]:
@@ -344,7 +354,7 @@ class GaussianDiffusion(nn.Module):
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
         guided = cond_scale != 1.0
         order = list(reversed(range(0, self.num_timesteps)))[:steps]
-        if not (isinstance(fn, Unet3D) and fn.has_cond and not self.use_dynamic_thres):
+        if not (isinstance(fn, Unet3D) and fn.has_cond):
             for k, i in enumerate(order):       # any other denoiser: call for call
                 t = torch.full((B,), i, device=device, dtype=torch.long)
                 nz = None if noises is None else noises[k].to(device)
@@ -395,7 +405,7 @@ class GaussianDiffusion(nn.Module):
         guided = frame_cond_scale != 1.0
         order = list(reversed(range(0, self.num_timesteps)))[:steps]
 
-        if not (isinstance(fn, Unet3D) and fn.has_frame_cross_attn and not fn.has_cond and not self.use_dynamic_thres):
+        if not (isinstance(fn, Unet3D) and fn.has_frame_cross_attn and not fn.has_cond):
             # any other denoiser: the reference's loop, call for call
             for k, i in enumerate(order):
                 t = torch.full((B,), i, device=device, dtype=torch.long)
