@@ -27,7 +27,7 @@ def per_kernel(dbpath, counter):
 
 
 def klass(name):
-    m = re.search(r"tapgemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+    m = re.search(r"tapgemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, \w+)*>", name)
     if m:
         return f"tapgemm<epi={m.group(6)},bn={m.group(2)}>"
     if "wsconv64_kernel" in name:
