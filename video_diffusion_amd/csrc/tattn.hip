@@ -47,6 +47,16 @@ struct TAttnArgs {
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+// Rotary and the score product in half precision (VDMI_TATTN_ROT16, default on): the projected q and k go to packed
+// f16 (11 significant bits against the 8 of the bf16 they were rounded to before), the rotation runs on pairs
+// (v_pk_mul_f16 / v_pk_fma_f16: 16 instructions per tensor instead of 32) and its results ARE the operands of
+// v_mfma_f32_32x32x16_f16 - no second conversion.  48 vector instructions per head instead of 80.
+#ifndef VDMI_TATTN_ROT16
+#define VDMI_TATTN_ROT16 1
+#endif
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
     bf16x8 f;
 #pragma unroll
@@ -132,6 +142,28 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
             rs[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+
+    // packed rotary factors of register pairs (2i, 2i+1), i = 0..3: plain for k, times the q scale for q
+    [[maybe_unused]] f16x2 rcp[4], rsp[4], rcq[4], rsq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rg = i >> 1, e = 2 * (i & 1);
+        rcp[i] = f16x2{(_Float16)rc[rg][e], (_Float16)rc[rg][e + 1]};
+        rsp[i] = f16x2{(_Float16)rs[rg][e], (_Float16)rs[rg][e + 1]};
+        rcq[i] = f16x2{(_Float16)(rc[rg][e] * qs), (_Float16)(rc[rg][e + 1] * qs)};
+        rsq[i] = f16x2{(_Float16)(rs[rg][e] * qs), (_Float16)(rs[rg][e + 1] * qs)};
+    }
+    // registers 0..7 (k-step 0) and 8..15 (k-step 1) of a projected tensor, rotated: the two f16 operand fragments
+    [[maybe_unused]] auto rotate16 = [](const f32x16& t, const f16x2 (&cc)[4], const f16x2 (&ss)[4], f16x8& f0, f16x8& f1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f16x2 lo = f16x2{(_Float16)t[2 * i], (_Float16)t[2 * i + 1]};
+            const f16x2 hi = f16x2{(_Float16)t[2 * i + 8], (_Float16)t[2 * i + 9]};
+            const f16x2 l2 = lo * cc[i] - hi * ss[i], h2 = hi * cc[i] + lo * ss[i];
+            f0[2 * i] = l2[0]; f0[2 * i + 1] = l2[1];
+            f1[2 * i] = h2[0]; f1[2 * i + 1] = h2[1];
+        }
+    };
 
     bf16x8 wreg[WP];
     auto load_slice = [&](int head) {
@@ -223,6 +255,11 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
                 for (int r = 0; r < 16; ++r) v[r] += v1[r];
             }
             // q scale (times log2 e) + half-split rotary (feature d pairs with d+16 = register r with r+8)
+#if VDMI_TATTN_ROT16
+            f16x8 qf0, qf1, kf0, kf1;
+            rotate16(q, rcq, rsq, qf0, qf1);
+            rotate16(k, rcp, rsp, kf0, kf1);
+#else
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
@@ -236,19 +273,30 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
                     k[r] = k1 * rc[rg][e] - k2 * rs[rg][e];
                     k[r + 8] = k2 * rc[rg][e] + k1 * rs[rg][e];
                 }
+#endif
             // ---- S^T = K Q^T, softmax over keys (this lane's 16 registers + the other half) --------
             f32x16 st;
             float mx = -1e30f;
             if constexpr (FOLD) {
                 const bf16x8 kx = *reinterpret_cast<const bf16x8*>(kxl + (head * 32 + l31) * 16 + 8 * half);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx, qx, zero, 0, 0, 0);          // bias + mask
+#if VDMI_TATTN_ROT16
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0, qf0, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qf1, st, 0, 0, 0);
+#else
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 0), acc_frag(q, 0), st, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 1), acc_frag(q, 1), st, 0, 0, 0);
+#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
             } else {
+#if VDMI_TATTN_ROT16
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0, qf0, zero, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qf1, st, 0, 0, 0);
+#else
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 0), acc_frag(q, 0), zero, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(k, 1), acc_frag(q, 1), st, 0, 0, 0);
+#endif
                 const float* bl = biasl + (head * F + q_f) * 32 + 4 * half;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
