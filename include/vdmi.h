@@ -247,6 +247,15 @@ int vdmi_tattn_fused(const void* x, void* y, const void* wpack, const float* bia
                      const float* rot_sin, int b, int f, int hw, int c, int heads, float q_scale, float eps,
                      const uint8_t* focus, vdmi_stream stream);
 
+/* The same layer for wide channel counts on small images (c in {256, 512}, heads = 8): one workgroup per two groups
+ * of floor(32/f) sites x f frames, one wave per head, the head's weight fragments streamed from memory into
+ * registers (they never pass through LDS).  Same arguments, same packed weights (vdmi_pack_tattn) and the same
+ * arithmetic as vdmi_tattn_fused; which of the two is faster depends on the rows per launch (this one below
+ * ~10k rows per sample batch of 8, where vdmi_tattn_fused would start too few workgroups). */
+int vdmi_tattn_fused_wide(const void* x, void* y, const void* wpack, const float* bias, const float* rot_cos,
+                          const float* rot_sin, int b, int f, int hw, int c, int heads, float q_scale, float eps,
+                          const uint8_t* focus, vdmi_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused Residual(PreNorm(SpatialLinearAttention)) (vdp.py:454-479, 331-337, 380-408): three
  * launches (k/v + context per frame, context fold into to_out, q + output) with x read twice and

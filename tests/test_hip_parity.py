@@ -264,6 +264,40 @@ def test_temporal_attention(tiny, name, key, c, div):
     assert rel_err(from_rows(y, B, Fr, h, h), ref) < LAYER_TOL
 
 
+@pytest.mark.parametrize("lvl,c,h,with_focus", [(1, 256, 7, False), (1, 256, 7, True), (2, 512, 5, False), (2, 512, 5, True),
+                                                (1, 256, 16, False)])
+def test_temporal_attention_wide_fused(lvl, c, h, with_focus):
+    """The one-launch temporal attention of the 256- and 512-channel levels (one wave per head, weights streamed into
+    registers) against the oracle, on images whose positions do not fill the last group of sites (7x7 = 49 and 5x5 = 25
+    positions at 6 sites per group, an odd number of groups per workgroup pair), with and without focus-present flags."""
+    kw = dict(dim=64, dim_mults=(1, 4, 8), channels=3)
+    m = make_unet(salt=11, **kw)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    B, Fr = 3, 5
+    L = Layers(m, B, Fr, 8, 8, torch.tensor([3, 400, 900]))
+    focus = torch.tensor([True, False, True]) if with_focus else None
+    if with_focus:
+        L.plan.focus_enabled = True
+        L.plan.focus_in.copy_(focus.to(torch.uint8).to(dev()))
+    x = bf16_round(inp(f"wide.tattn.{c}.{h}", (B, c, Fr, h, h), scale=1.3))
+    name = f"downs.{lvl}.3"
+    ncalls = []
+
+    def build(plan, P):
+        out = plan._attention(name, P["downs"][lvl]["tattn"], to_rows(x), c, h, h, True, focus=with_focus)
+        ncalls.append(len(plan.calls))
+        return out
+
+    y = L.run(build)
+    assert ncalls == [1]                    # one launch
+    bias = O.relpos_bias(sd["time_rel_pos_bias.relative_attention_bias.weight"], Fr, 32, 32)
+    ref = O.temporal_attn_residual(sd, name, x, oracle_cfg(**kw), bias, focus)
+    assert record(f"tattn_wide_c{c}_h{h}_focus{int(with_focus)}", rel_err(from_rows(y, B, Fr, h, h), ref), LAYER_TOL) < LAYER_TOL
+    if with_focus:
+        plain = O.temporal_attn_residual(sd, name, x, oracle_cfg(**kw), bias, None)
+        assert rel_err(ref, plain) > 1e-3
+
+
 def test_temporal_attention_interleaved_rotary():
     """The interleaved rotary pairing (served by de-interleaving the q / k projection rows at packing time)
     against the oracle's restatement of it, on the fused kernel."""

@@ -54,7 +54,7 @@ def main():
         for f in files:
             out = os.path.join(tmp, os.path.basename(f) + ".s")
             # the flags of csrc/Makefile, per file (the attention kernels are built without SLP vectorisation)
-            extra = ["-fno-slp-vectorize"] if os.path.basename(f).split(".")[0] in ("tattn", "sla", "attn", "xattn") else []
+            extra = ["-fno-slp-vectorize"] if os.path.basename(f).split(".")[0] in ("tattn", "tattnw", "sla", "attn", "xattn") else []
             subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, f, "-o", out] + extra,
                            check=True, stderr=subprocess.DEVNULL)

@@ -352,15 +352,16 @@ class Plan:
         frames, hw = self.B * self.F, h * w
         rows = frames * hw
         hid = at["hid"]
-        # the 256-channel form of the fused kernel runs one wave per SIMD and streams 64 KB of weights per head: it
-        # pays on 16x16 images (34 us against 58 for the three launches at 8 samples), not on 8x8 (33 against 30).
-        # Decided by the image, never by the batch, so a sample's bits do not depend on the batch.
-        if temporal and at.get("fused") is not None and self.F <= 32 and (c < 256 or hw >= 256):
+        # 256 and 512 channels: the wide form of the fused kernel (one wave per head, weights streamed into registers).
+        # The choice depends on the layer's shape only, never on the batch, so a sample's bits do not depend on the batch.
+        wide = hid == 256 and (c == 512 or (c == 256 and hw < TATTN_WIDE_BELOW_HW))
+        if temporal and at.get("fused") is not None and self.F <= 32 and (c < 256 or hw >= 256 or wide):
             y = self._buf(rows, c)
             wp = at["fused"]
             meta = {"kernel": "tattn_fused", "flops": 2.0 * rows * c * 4 * hid + 4.0 * rows * self.F * hid,
                     "bytes": 4.0 * rows * c}
-            self._add(lambda s, x=x, y=y: lib.vdmi_tattn_fused(
+            fn = lib.vdmi_tattn_fused_wide if wide else lib.vdmi_tattn_fused
+            self._add(lambda s, x=x, y=y: fn(
                 x.data_ptr(), y.data_ptr(), wp.data_ptr(), _ptr(self.pos_bias), _ptr(self.rot_cos),
                 _ptr(self.rot_sin), self.B, self.F, hw, c, hid // 32, at["scale"], 1e-5, fptr, s), meta, name + ".fused")
             return y
@@ -656,7 +657,11 @@ class Plan:
 
 
 # channel widths whose temporal attention runs as the one fused kernel (VDMI_TATTN_256=0: 256 stays on the three-launch path)
-FUSED_TATTN_CHANNELS = (32, 64, 128) + ((256,) if os.environ.get("VDMI_TATTN_256", "1") != "0" else ())
+FUSED_TATTN_CHANNELS = (32, 64, 128) + ((256,) if os.environ.get("VDMI_TATTN_256", "1") != "0" else ()) + \
+    ((512,) if os.environ.get("VDMI_TATTN_WIDE", "1") != "0" else ())
+# 256-channel temporal attention on images of fewer positions than this runs on the wide fused kernel (0: never).
+# Measured at 8 samples per launch: 8x8 30 (three launches) -> 13.6 us, 16x16 36 (tattn_fused) -> 28 us.
+TATTN_WIDE_BELOW_HW = int(os.environ.get("VDMI_TATTN_WIDE_BELOW_HW", str(1 << 30))) if os.environ.get("VDMI_TATTN_WIDE", "1") != "0" else 0
 # wide-layer convs that would launch fewer workgroups than this split their contraction (0: never)
 K_SPLIT_BELOW = int(os.environ.get("VDMI_K_SPLIT_BELOW", "256"))
 K_SPLIT_TARGET = int(os.environ.get("VDMI_K_SPLIT_TARGET", "320"))      # workgroups per launch the split aims at
