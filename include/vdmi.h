@@ -256,6 +256,13 @@ int vdmi_tattn_fused_wide(const void* x, void* y, const void* wpack, const float
                           const float* rot_sin, int b, int f, int hw, int c, int heads, float q_scale, float eps,
                           const uint8_t* focus, vdmi_stream stream);
 
+/* Residual(PreNorm(EinopsToAndFrom('b c f h w', 'b f (h w) c', Attention))) of the mid block (vdp.py:708-710, 531-612
+ * without rotary and bias) in one launch, on the same kernel family: full softmax attention over the hw <= 64
+ * positions of each frame, one workgroup per frame, one wave per head; x, y: bf16 [frames*hw][c], c in {256, 512},
+ * heads = 8, wpack from vdmi_pack_tattn (to_qkv with the LayerNorm gamma folded in, to_out). */
+int vdmi_sattn_fused_wide(const void* x, void* y, const void* wpack, int frames, int hw, int c, int heads,
+                          float q_scale, float eps, vdmi_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused Residual(PreNorm(SpatialLinearAttention)) (vdp.py:454-479, 331-337, 380-408): three
  * launches (k/v + context per frame, context fold into to_out, q + output) with x read twice and

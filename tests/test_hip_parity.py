@@ -326,6 +326,30 @@ def test_mid_spatial_attention(tiny):
     assert rel_err(from_rows(y, B, Fr, h, h), ref) < LAYER_TOL
 
 
+@pytest.mark.parametrize("mults,c,h", [((1, 4, 8), 512, 8), ((1, 4, 8), 512, 5), ((1, 4), 256, 8), ((1, 4), 256, 3)])
+def test_mid_spatial_attention_wide_fused(mults, c, h):
+    """The mid-block spatial attention at 256 / 512 channels as one launch (a workgroup per frame, a wave per head),
+    on full 8x8 frames and on frames of 25 and 9 positions (keys past the frame masked, second tile partly / wholly
+    empty), against the oracle."""
+    kw = dict(dim=64, dim_mults=mults, channels=3)
+    m = make_unet(salt=13, **kw)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    B, Fr = 2, 3
+    L = Layers(m, B, Fr, 8, 8, torch.tensor([3, 900]))
+    x = bf16_round(inp(f"wide.sattn.{c}.{h}", (B, c, Fr, h, h), scale=1.3))
+    ncalls = []
+
+    def build(plan, P):
+        out = plan._sta("mid_spatial_attn", P["mid_spatial_attn"], to_rows(x), c, h, h, per_frame=True)
+        ncalls.append(len(plan.calls))
+        return out
+
+    y = L.run(build)
+    assert ncalls == [1]                    # one launch
+    ref = O.spatial_attn_residual(sd, "mid_spatial_attn", x, oracle_cfg(**kw))
+    assert record(f"sattn_wide_c{c}_h{h}", rel_err(from_rows(y, B, Fr, h, h), ref), LAYER_TOL) < LAYER_TOL
+
+
 @pytest.mark.parametrize("lvl,key,c,div", [(0, "a32", 32, 1), (1, "a64h", 64, 2)])
 def test_spatial_linear_attention(tiny, lvl, key, c, div):
     L, sd, cfg, B, Fr, H = tiny["L"], tiny["sd"], tiny["cfg"], tiny["B"], tiny["F"], tiny["H"]

@@ -49,7 +49,10 @@ constexpr int TW_NT = 2;        // 32-row groups per workgroup
 constexpr int TW_HEADS = 8;     // one wave per head
 constexpr int TW_PD = 4;        // k-steps of weight fragments in flight per wave
 
-template <int C, bool FOLD>
+// MODE 0: attention over the frames of each site (temporal).  MODE 1: full softmax attention over the positions of one
+// frame (the mid-block spatial attention, vdp.py:708-710: no rotary, no bias, no focus flags): a workgroup is one frame
+// of at most 64 positions, its two 32-row tiles are the frame's key / query halves.
+template <int C, bool FOLD, int MODE = 0>
 __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs a) {
     constexpr int KS = C / 16, CT = C / 32, NFRAG = 3 * KS + 2 * CT, SLICE = NFRAG * 512;
     constexpr int XROW = C + 8, OROW = TW_HEADS * 32 + 8, NT = TW_NT, NTHR = TW_HEADS * 64;
@@ -64,7 +67,8 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
     const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int F = a.F, g = a.sites_per_group;
 
-    if constexpr (FOLD) {
+    if constexpr (MODE == 1) {
+    } else if constexpr (FOLD) {
         for (int i = tid; i < TW_HEADS * 512; i += NTHR) {
             const int slot = i & 15, row = (i >> 4) & 31, hd = i >> 9;
             const bool valid = row < g * F;
@@ -84,12 +88,20 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
     // ---- phase 0: rows -> LayerNorm -> LDS.  Thread t loads pieces (t & 7) + 8 i of row t >> 3.
     {
         const int rr = tid >> 3, tile = rr >> 5, rl = rr & 31;
-        const int grp = blockIdx.x * NT + tile;
-        const int b = grp / a.groups_per_sample;
-        const int site = rl / F, fr = rl - site * F;
-        const int s = (grp - b * a.groups_per_sample) * g + site;
-        const bool ok = grp < a.ngroups && site < g && s < a.HW;
-        const __bf16* src = a.x + (ok ? ((long long)b * F + fr) * a.HW + s : 0) * C;
+        bool ok;
+        long long srow;
+        if constexpr (MODE == 1) {
+            ok = rr < a.HW;
+            srow = (long long)blockIdx.x * a.HW + rr;
+        } else {
+            const int grp = blockIdx.x * NT + tile;
+            const int b = grp / a.groups_per_sample;
+            const int site = rl / F, fr = rl - site * F;
+            const int s = (grp - b * a.groups_per_sample) * g + site;
+            ok = grp < a.ngroups && site < g && s < a.HW;
+            srow = ((long long)b * F + fr) * a.HW + s;
+        }
+        const __bf16* src = a.x + (ok ? srow : 0) * C;
         bf16x8 pv[PPT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -129,12 +141,18 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int grp = blockIdx.x * NT + t;
-            const int b = grp / a.groups_per_sample;
-            const int s = (grp - b * a.groups_per_sample) * g + q_site;
-            rowvalid[t] = grp < a.ngroups && q_site < g && s < a.HW;
-            grow[t] = rowvalid[t] ? ((long long)b * F + q_f) * a.HW + s : 0;
-            kmask[t] = (a.focus && grp < a.ngroups && a.focus[b]) ? kmask_self : kmask_all;
+            if constexpr (MODE == 1) {
+                rowvalid[t] = t * 32 + l31 < a.HW;
+                grow[t] = rowvalid[t] ? (long long)blockIdx.x * a.HW + t * 32 + l31 : 0;
+                kmask[t] = 0;
+            } else {
+                const int grp = blockIdx.x * NT + t;
+                const int b = grp / a.groups_per_sample;
+                const int s = (grp - b * a.groups_per_sample) * g + q_site;
+                rowvalid[t] = grp < a.ngroups && q_site < g && s < a.HW;
+                grow[t] = rowvalid[t] ? ((long long)b * F + q_f) * a.HW + s : 0;
+                kmask[t] = (a.focus && grp < a.ngroups && a.focus[b]) ? kmask_self : kmask_all;
+            }
         }
     }
     bf16x8 qx = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -211,7 +229,62 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
         }
     }
 
-    // ---- phase 2: attention of this head, group by group; O^T -> LDS in the to_out fragments' k-slot order
+    // ---- phase 2: attention of this head; O^T -> LDS in the to_out fragments' k-slot order
+    if constexpr (MODE == 1) {
+        // operands of the score product in f16, q times scale * log2 e
+        const f16x2 qs2 = f16x2{(_Float16)qs, (_Float16)qs};
+        f16x8 qf[NT][2], kf[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f16x2 q2 = f16x2{(_Float16)qT[t][8 * s + 2 * i], (_Float16)qT[t][8 * s + 2 * i + 1]} * qs2;
+                    const f16x2 k2 = f16x2{(_Float16)kT[t][8 * s + 2 * i], (_Float16)kT[t][8 * s + 2 * i + 1]};
+                    qf[t][s][2 * i] = q2[0]; qf[t][s][2 * i + 1] = q2[1];
+                    kf[t][s][2 * i] = k2[0]; kf[t][s][2 * i + 1] = k2[1];
+                }
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            f32x16 st[NT];
+            float mx = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][0], qf[qt][0], zero, 0, 0, 0);
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][1], qf[qt][1], st[kt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (kt * 32 + acc_row(r, half) >= a.HW) st[kt][r] = -1e30f;      // keys past the frame
+                    mx = fmaxf(mx, st[kt][r]);
+                }
+            mx = xhalf_max(mx);
+            float lsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(st[kt][r] - mx);
+                    st[kt][r] = p;
+                    lsum += p;
+                }
+            lsum = xhalf_add(lsum);
+            f32x16 o = zero, o1 = zero;      // two accumulators: neighbouring MFMAs stay independent
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vv[0], 0), acc_frag(st[0], 0), o, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vv[1], 0), acc_frag(st[1], 0), o1, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vv[0], 1), acc_frag(st[0], 1), o, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(vv[1], 1), acc_frag(st[1], 1), o1, 0, 0, 0);
+            const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = (o[r] + o1[r]) * inv;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                *reinterpret_cast<bf16x8*>(os + (qt * 32 + l31) * OROW + head * 32 + s * 16 + 8 * half) = acc_frag(o, s);
+        }
+    } else
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         f16x8 qf0, qf1, kf0, kf1;
@@ -297,6 +370,41 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
 }
 
 }   // namespace
+
+extern "C" int vdmi_sattn_fused_wide(const void* x, void* y, const void* wpack, int frames, int hw, int c, int heads,
+                                     float q_scale, float eps, vdmi_stream stream_) {
+    if (!x || !y || !wpack) return VDMI_E_ARG;
+    if (frames <= 0 || hw <= 0 || hw > TW_NT * 32 || (c != 256 && c != 512) || heads != TW_HEADS) return VDMI_E_SHAPE;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(wpack)) return VDMI_E_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    TWArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = static_cast<const __bf16*>(x);
+    a.y = static_cast<__bf16*>(y);
+    a.w = static_cast<const __bf16*>(wpack);
+    a.F = 1;
+    a.HW = hw;
+    a.heads = heads;
+    a.sites_per_group = 32;
+    a.groups_per_sample = 1;
+    a.ngroups = frames;
+    a.q_scale = q_scale;
+    a.eps = eps;
+    const size_t lds = (size_t)TW_NT * 32 * (c + 8) * 2 + (size_t)TW_NT * 32 * (TW_HEADS * 32 + 8) * 2;
+#define VDMI_SW_CASE(C_)                                                                                            \
+    if (c == C_) {                                                                                                  \
+        static std::atomic<uint64_t> attr_mask{0};                                                                  \
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(tattn_wide_kernel<C_, false, 1>), attr_mask, 160 * 1024)) \
+            return VDMI_E_LAUNCH;                                                                                   \
+        hipLaunchKernelGGL((tattn_wide_kernel<C_, false, 1>), dim3(frames), dim3(TW_HEADS * 64), lds, stream, a);   \
+        VDMI_LAUNCH_CHECK();                                                                                        \
+        return VDMI_OK;                                                                                             \
+    }
+    VDMI_SW_CASE(256)
+    VDMI_SW_CASE(512)
+#undef VDMI_SW_CASE
+    return VDMI_E_SHAPE;
+}
 
 extern "C" int vdmi_tattn_fused_wide(const void* x, void* y, const void* wpack, const float* bias, const float* rot_cos,
                                      const float* rot_sin, int b, int f, int hw, int c, int heads, float q_scale,

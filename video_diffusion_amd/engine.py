@@ -323,6 +323,13 @@ class Plan:
         rows, hid = frames * hw, st["hid"]
         n_tok, ngrp = (hw, frames) if per_frame else (self.F * hw, self.B)
         heads = hid // 32
+        if per_frame and st.get("fused") is not None and hw <= 64:
+            y = self._buf(rows, c)
+            wp = st["fused"]
+            meta = {"kernel": "sattn_fused", "flops": 2.0 * rows * c * 4 * hid + 4.0 * rows * hw * hid, "bytes": 4.0 * rows * c}
+            self._add(lambda s, x=x, y=y: lib.vdmi_sattn_fused_wide(
+                x.data_ptr(), y.data_ptr(), wp.data_ptr(), frames, hw, c, heads, st["scale"], 1e-5, s), meta, name + ".fused")
+            return y
         qkv = self._buf(rows, 3 * hid)
         a = self._base_args(frames, h, w, qkv, 3 * hid, EPI_QKV_ATTN)
         _fill_pass(a.main, x, c, None, 0, h, w, 1, [(0, 0)], st["wqkv"].data)
@@ -905,7 +912,16 @@ class UnetEngine:
         perm = torch.tensor([32 * hd + (r & 3) + 8 * (r >> 2) + 4 * hh
                              for hd in range(hid // 32) for hh in (0, 1) for r in range(16)])
         wo = st.to_out.weight.detach().float().cpu()[:, perm]
-        return {"sta": True, "hid": hid, "scale": float(st.scale),
+        fused = None
+        cdim = wq.shape[1]
+        if cdim in (256, 512) and hid == 256 and TATTN_WIDE_BELOW_HW:
+            # per-frame attention over at most 64 positions: the one-launch kernel (weights in vdmi_pack_tattn order)
+            lib = _lib.lib()
+            buf = torch.empty(lib.vdmi_pack_tattn_elems(cdim, hid // 32), dtype=torch.int16)
+            wqc, won = wq.contiguous(), st.to_out.weight.detach().float().cpu().contiguous()
+            check(lib.vdmi_pack_tattn(wqc.data_ptr(), won.data_ptr(), cdim, hid // 32, buf.data_ptr()), "vdmi_pack_tattn")
+            fused = buf.view(torch.bfloat16).to(device)
+        return {"sta": True, "hid": hid, "scale": float(st.scale), "fused": fused,
                 "wqkv": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_ATTN, device, want_colsum=True),
                 "wout": PackedTaps(wo[:, :, None], hid, 0, EPI_PLAIN, device)}
 
