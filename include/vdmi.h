@@ -277,6 +277,12 @@ int vdmi_sla_fused(const void* x, void* y, const void* wpack, const float* w_out
                    void* workspace, int frames, int hw, int c, int heads, float q_scale, float eps,
                    vdmi_stream stream);
 
+/* The same layer in ONE launch for wide channel counts on small frames (c in {256, 512}, heads = 8, hw <= 64): a
+ * workgroup per frame, a wave per head, the 32 x 32 context kept in registers.  wpack: vdmi_pack_tattn of to_qkv (with
+ * the LayerNorm gamma folded in) and to_out; b_out: float [c] or NULL. */
+int vdmi_sla_fused_wide(const void* x, void* y, const void* wpack, const float* b_out, int frames, int hw, int c,
+                        int heads, float q_scale, float eps, vdmi_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * SpatialLinearAttention pass 1 (vdp.py:471-476): per (frame, head) softmax of k over the
  * n = H*W positions, context = k·vᵀ (32x32), folded into the output projection:

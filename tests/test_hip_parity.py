@@ -350,6 +350,29 @@ def test_mid_spatial_attention_wide_fused(mults, c, h):
     assert record(f"sattn_wide_c{c}_h{h}", rel_err(from_rows(y, B, Fr, h, h), ref), LAYER_TOL) < LAYER_TOL
 
 
+@pytest.mark.parametrize("lvl,c,h", [(2, 512, 8), (2, 512, 5), (1, 256, 8), (1, 256, 3)])
+def test_spatial_linear_attention_wide_fused(lvl, c, h):
+    """SpatialLinearAttention at 256 / 512 channels as one launch (a workgroup per frame, a wave per head, the context in
+    registers), on full 8x8 frames and on frames of 25 and 9 positions, against the oracle."""
+    kw = dict(dim=64, dim_mults=(1, 4, 8), channels=3)
+    m = make_unet(salt=17, **kw)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    B, Fr = 2, 3
+    L = Layers(m, B, Fr, 8, 8, torch.tensor([3, 900]))
+    x = bf16_round(inp(f"wide.sla.{c}.{h}", (B, c, Fr, h, h), scale=1.3))
+    ncalls = []
+
+    def build(plan, P):
+        out = plan._sla(f"downs.{lvl}.2", P["downs"][lvl]["sla"], to_rows(x), c, h, h)
+        ncalls.append(len(plan.calls))
+        return out
+
+    y = L.run(build)
+    assert ncalls == [1]                    # one launch
+    ref = O.sla_residual(sd, f"downs.{lvl}.2", x, oracle_cfg(**kw))
+    assert record(f"sla_wide_c{c}_h{h}", rel_err(from_rows(y, B, Fr, h, h), ref), LAYER_TOL) < LAYER_TOL
+
+
 @pytest.mark.parametrize("lvl,key,c,div", [(0, "a32", 32, 1), (1, "a64h", 64, 2)])
 def test_spatial_linear_attention(tiny, lvl, key, c, div):
     L, sd, cfg, B, Fr, H = tiny["L"], tiny["sd"], tiny["cfg"], tiny["B"], tiny["F"], tiny["H"]

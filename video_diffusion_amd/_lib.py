@@ -89,6 +89,7 @@ _SIGNATURES = {
     "vdmi_tattn_fused": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "vdmi_tattn_fused_wide": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "vdmi_sattn_fused_wide": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_void_p]),
+    "vdmi_sla_fused_wide": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_void_p]),
     "vdmi_pack_sla_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "vdmi_pack_sla": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vdmi_sla_workspace_bytes": (C.c_size_t, [C.c_int] * 4),

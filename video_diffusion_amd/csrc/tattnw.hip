@@ -28,6 +28,7 @@ struct TWArgs {
     const float* rot_cos;   // [F][16] or null
     const float* rot_sin;
     const uint8_t* focus;   // [B] or null
+    const float* b_out;     // [C] or null: bias of to_out (the linear-attention layer has one)
     int F, HW, heads;
     int sites_per_group, groups_per_sample, ngroups;
     float q_scale, eps;
@@ -51,7 +52,9 @@ constexpr int TW_PD = 4;        // k-steps of weight fragments in flight per wav
 
 // MODE 0: attention over the frames of each site (temporal).  MODE 1: full softmax attention over the positions of one
 // frame (the mid-block spatial attention, vdp.py:708-710: no rotary, no bias, no focus flags): a workgroup is one frame
-// of at most 64 positions, its two 32-row tiles are the frame's key / query halves.
+// of at most 64 positions, its two 32-row tiles are the frame's key / query halves.  MODE 2: SpatialLinearAttention
+// (vdp.py:454-479) over such a frame: q softmax over the head's 32 features, k softmax over the positions,
+// context = k^T v (32 x 32, in registers), out = q context, to_out with bias.
 template <int C, bool FOLD, int MODE = 0>
 __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs a) {
     constexpr int KS = C / 16, CT = C / 32, NFRAG = 3 * KS + 2 * CT, SLICE = NFRAG * 512;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
     const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int F = a.F, g = a.sites_per_group;
 
-    if constexpr (MODE == 1) {
+    if constexpr (MODE != 0) {
     } else if constexpr (FOLD) {
         for (int i = tid; i < TW_HEADS * 512; i += NTHR) {
             const int slot = i & 15, row = (i >> 4) & 31, hd = i >> 9;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
         const int rr = tid >> 3, tile = rr >> 5, rl = rr & 31;
         bool ok;
         long long srow;
-        if constexpr (MODE == 1) {
+        if constexpr (MODE != 0) {
             ok = rr < a.HW;
             srow = (long long)blockIdx.x * a.HW + rr;
         } else {
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if constexpr (MODE == 1) {
+            if constexpr (MODE != 0) {
                 rowvalid[t] = t * 32 + l31 < a.HW;
                 grow[t] = rowvalid[t] ? (long long)blockIdx.x * a.HW + t * 32 + l31 : 0;
                 kmask[t] = 0;
@@ -219,7 +222,9 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             qT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[u], xb[t], qT[t], 0, 0, 0);
-            kT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[u], xb[t], kT[t], 0, 0, 0);
+            // linear attention wants K like V: positions in the registers, the head's feature on the lane
+            if constexpr (MODE == 2) kT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[t], wk[u], kT[t], 0, 0, 0);
+            else kT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[u], xb[t], kT[t], 0, 0, 0);
             vv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[t], wv[u], vv[t], 0, 0, 0);
         }
         if (ks + TW_PD < KS) {
@@ -230,7 +235,67 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
     }
 
     // ---- phase 2: attention of this head; O^T -> LDS in the to_out fragments' k-slot order
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 2) {
+        // k: softmax over the frame's positions, per feature d = this lane's column (rows past the frame weigh nothing)
+        float mx = -1e30f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (t * 32 + acc_row(r, half) >= a.HW) kT[t][r] = -1e30f;
+                mx = fmaxf(mx, kT[t][r]);
+            }
+        mx = xhalf_max(mx);
+        const float mxl = mx * LOG2E;
+        float lsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(kT[t][r], LOG2E, -mxl));
+                kT[t][r] = e;
+                lsum += e;
+            }
+        lsum = xhalf_add(lsum);
+        const float kinv = 1.0f / lsum;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kT[t][r] *= kinv;
+        // context[d][e] = sum_n k[n][d] v[n][e]: d in the registers, e on the lanes (one accumulator per tile, so that
+        // neighbouring MFMAs are independent)
+        f32x16 ctx = zero, ctx1 = zero;
+        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(kT[0], 0), acc_frag(vv[0], 0), ctx, 0, 0, 0);
+        ctx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(kT[1], 0), acc_frag(vv[1], 0), ctx1, 0, 0, 0);
+        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(kT[0], 1), acc_frag(vv[0], 1), ctx, 0, 0, 0);
+        ctx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(kT[1], 1), acc_frag(vv[1], 1), ctx1, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctx[r] += ctx1[r];
+        const bf16x8 c0 = acc_frag(ctx, 0), c1 = acc_frag(ctx, 1);
+        // position of feature e = l31 inside a row's 32 k-slots of this head (see phase 3's fragment order)
+        const int ee = l31 & 15, epos = (l31 >> 4) * 16 + ((ee >> 2) & 1) * 8 + (ee & 3) + 4 * (ee >> 3);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // q: softmax over the head's 32 features (16 registers here, 16 in lane ^ 32), times the scale
+            float qm = qT[t][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) qm = fmaxf(qm, qT[t][r]);
+            qm = xhalf_max(qm);
+            const float qml = qm * LOG2E;
+            float qsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { qT[t][r] = __builtin_amdgcn_exp2f(fmaf(qT[t][r], LOG2E, -qml)); qsum += qT[t][r]; }
+            qsum = xhalf_add(qsum);
+            const float qinv = a.q_scale / qsum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qT[t][r] *= qinv;
+            // out[n][e] = sum_d q[n][d] context[d][e]: rows n in the registers, e on the lanes
+            f32x16 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(qT[t], 0), c0, zero, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(qT[t], 1), c1, o, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) os[(t * 32 + acc_row(r, half)) * OROW + head * 32 + epos] = f2bf(o[r]);
+        }
+    } else if constexpr (MODE == 1) {
         // operands of the score product in f16, q times scale * log2 e
         const f16x2 qs2 = f16x2{(_Float16)qs, (_Float16)qs};
         f16x8 qf[NT][2], kf[NT][2];
@@ -359,9 +424,14 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
                 for (int kl = 0; kl < 2; ++kl) {
                     const long long off = grow[t] * C + (2 * ct + kl) * 16 + 8 * half;
                     const bf16x8 xr = *reinterpret_cast<const bf16x8*>(a.x + off);
+                    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+                    if (MODE == 2 && a.b_out) {
+                        b0 = *reinterpret_cast<const f32x4*>(a.b_out + (2 * ct + kl) * 16 + 8 * half);
+                        b1 = *reinterpret_cast<const f32x4*>(a.b_out + (2 * ct + kl) * 16 + 8 * half + 4);
+                    }
                     bf16x8 out;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) out[e] = f2bf(yacc[t][8 * kl + e] + (float)xr[e]);
+                    for (int e = 0; e < 8; ++e) out[e] = f2bf(yacc[t][8 * kl + e] + (e < 4 ? b0[e & 3] : b1[e & 3]) + (float)xr[e]);
                     *reinterpret_cast<bf16x8*>(a.y + off) = out;
                 }
             }
@@ -371,8 +441,8 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
 
 }   // namespace
 
-extern "C" int vdmi_sattn_fused_wide(const void* x, void* y, const void* wpack, int frames, int hw, int c, int heads,
-                                     float q_scale, float eps, vdmi_stream stream_) {
+static int frame_attention_wide(int mode, const void* x, void* y, const void* wpack, const float* b_out, int frames, int hw,
+                                int c, int heads, float q_scale, float eps, vdmi_stream stream_) {
     if (!x || !y || !wpack) return VDMI_E_ARG;
     if (frames <= 0 || hw <= 0 || hw > TW_NT * 32 || (c != 256 && c != 512) || heads != TW_HEADS) return VDMI_E_SHAPE;
     if (!aligned16(x) || !aligned16(y) || !aligned16(wpack)) return VDMI_E_ALIGN;
@@ -382,6 +452,7 @@ extern "C" int vdmi_sattn_fused_wide(const void* x, void* y, const void* wpack, 
     a.x = static_cast<const __bf16*>(x);
     a.y = static_cast<__bf16*>(y);
     a.w = static_cast<const __bf16*>(wpack);
+    a.b_out = b_out;
     a.F = 1;
     a.HW = hw;
     a.heads = heads;
@@ -391,19 +462,32 @@ extern "C" int vdmi_sattn_fused_wide(const void* x, void* y, const void* wpack, 
     a.q_scale = q_scale;
     a.eps = eps;
     const size_t lds = (size_t)TW_NT * 32 * (c + 8) * 2 + (size_t)TW_NT * 32 * (TW_HEADS * 32 + 8) * 2;
-#define VDMI_SW_CASE(C_)                                                                                            \
-    if (c == C_) {                                                                                                  \
-        static std::atomic<uint64_t> attr_mask{0};                                                                  \
-        if (vdmi_set_max_lds(reinterpret_cast<const void*>(tattn_wide_kernel<C_, false, 1>), attr_mask, 160 * 1024)) \
-            return VDMI_E_LAUNCH;                                                                                   \
-        hipLaunchKernelGGL((tattn_wide_kernel<C_, false, 1>), dim3(frames), dim3(TW_HEADS * 64), lds, stream, a);   \
-        VDMI_LAUNCH_CHECK();                                                                                        \
-        return VDMI_OK;                                                                                             \
+#define VDMI_SW_CASE(C_, MODE_)                                                                                         \
+    if (c == C_ && mode == MODE_) {                                                                                     \
+        static std::atomic<uint64_t> attr_mask{0};                                                                      \
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(tattn_wide_kernel<C_, false, MODE_>), attr_mask, 160 * 1024)) \
+            return VDMI_E_LAUNCH;                                                                                       \
+        hipLaunchKernelGGL((tattn_wide_kernel<C_, false, MODE_>), dim3(frames), dim3(TW_HEADS * 64), lds, stream, a);   \
+        VDMI_LAUNCH_CHECK();                                                                                            \
+        return VDMI_OK;                                                                                                 \
     }
-    VDMI_SW_CASE(256)
-    VDMI_SW_CASE(512)
+    VDMI_SW_CASE(256, 1)
+    VDMI_SW_CASE(512, 1)
+    VDMI_SW_CASE(256, 2)
+    VDMI_SW_CASE(512, 2)
 #undef VDMI_SW_CASE
     return VDMI_E_SHAPE;
+}
+
+extern "C" int vdmi_sattn_fused_wide(const void* x, void* y, const void* wpack, int frames, int hw, int c, int heads,
+                                     float q_scale, float eps, vdmi_stream stream) {
+    return frame_attention_wide(1, x, y, wpack, nullptr, frames, hw, c, heads, q_scale, eps, stream);
+}
+
+extern "C" int vdmi_sla_fused_wide(const void* x, void* y, const void* wpack, const float* b_out, int frames, int hw, int c,
+                                   int heads, float q_scale, float eps, vdmi_stream stream) {
+    if (b_out && !aligned16(b_out)) return VDMI_E_ALIGN;
+    return frame_attention_wide(2, x, y, wpack, b_out, frames, hw, c, heads, q_scale, eps, stream);
 }
 
 extern "C" int vdmi_tattn_fused_wide(const void* x, void* y, const void* wpack, const float* bias, const float* rot_cos,
@@ -422,6 +506,7 @@ extern "C" int vdmi_tattn_fused_wide(const void* x, void* y, const void* wpack, 
     a.rot_cos = rot_cos;
     a.rot_sin = rot_sin;
     a.focus = focus;
+    a.b_out = nullptr;
     a.F = f;
     a.HW = hw;
     a.heads = heads;

@@ -414,6 +414,14 @@ class Plan:
                 x.data_ptr(), y.data_ptr(), wp.data_ptr(), wout.data_ptr(), bout.data_ptr(), ws.data_ptr(),
                 frames, hw, c, heads, sl["scale"], 1e-5, s), meta, name + ".fused")
             return y
+        if sl.get("fused_wide") is not None and hw <= 64:
+            y = self._buf(rows, c)
+            wp, bout = sl["fused_wide"], sl["bout"]
+            meta = {"kernel": "sla_fused_wide", "flops": 2.0 * rows * c * 4 * hid + 4.0 * rows * 32 * hid, "bytes": 4.0 * rows * c}
+            self._add(lambda s, x=x, y=y: lib.vdmi_sla_fused_wide(
+                x.data_ptr(), y.data_ptr(), wp.data_ptr(), bout.data_ptr(), frames, hw, c, heads, sl["scale"], 1e-5, s),
+                meta, name + ".fused")
+            return y
         qs = self._buf(rows, hid)
         kvt = torch.empty(frames, 2 * hid, hw, device=self.device, dtype=torch.bfloat16)
         self.keep.append(kvt)
@@ -941,8 +949,18 @@ class UnetEngine:
             wqc = wq.contiguous()
             check(lib.vdmi_pack_sla(wqc.data_ptr(), cdim, hid // 32, buf.data_ptr()), "vdmi_pack_sla")
             fused = buf.view(torch.bfloat16).to(device)
+        fused_wide = None
+        if cdim in (256, 512) and hid == 256 and TATTN_WIDE_BELOW_HW:
+            # frames of at most 64 positions: the one-launch kernel (weights in vdmi_pack_tattn order)
+            lib = _lib.lib()
+            buf = torch.empty(lib.vdmi_pack_tattn_elems(cdim, hid // 32), dtype=torch.int16)
+            wqc = wq.contiguous()
+            won = sl.to_out.weight.detach().float().cpu().reshape(sl.to_out.weight.shape[0], -1).contiguous()
+            check(lib.vdmi_pack_tattn(wqc.data_ptr(), won.data_ptr(), cdim, hid // 32, buf.data_ptr()), "vdmi_pack_tattn")
+            fused_wide = buf.view(torch.bfloat16).to(device)
         return {
             "fused": fused,
+            "fused_wide": fused_wide,
             "wqkv": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_SLA, device, want_colsum=True),
             "wout_f32": sl.to_out.weight.detach().float().reshape(sl.to_out.weight.shape[0], -1).to(device).contiguous(),
             "bout": sl.to_out.bias.detach().float().to(device).contiguous(),
