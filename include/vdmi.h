@@ -277,8 +277,9 @@ int vdmi_sla_fused(const void* x, void* y, const void* wpack, const float* w_out
                    void* workspace, int frames, int hw, int c, int heads, float q_scale, float eps,
                    vdmi_stream stream);
 
-/* The same layer in ONE launch for wide channel counts on small frames (c in {256, 512}, heads = 8, hw <= 64): a
- * workgroup per frame, a wave per head, the 32 x 32 context kept in registers.  wpack: vdmi_pack_tattn of to_qkv (with
+/* The same layer in ONE launch for wide channel counts (c in {256, 512}, heads = 8): a workgroup per frame, a wave per
+ * head, the 32 x 32 context kept in registers; frames of more than 64 positions are swept twice in pairs of 32-row
+ * tiles (k, v and the context with an online softmax over the positions, then q and the output; c = 256 only).  wpack: vdmi_pack_tattn of to_qkv (with
  * the LayerNorm gamma folded in) and to_out; b_out: float [c] or NULL. */
 int vdmi_sla_fused_wide(const void* x, void* y, const void* wpack, const float* b_out, int frames, int hw, int c,
                         int heads, float q_scale, float eps, vdmi_stream stream);

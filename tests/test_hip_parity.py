@@ -350,10 +350,11 @@ def test_mid_spatial_attention_wide_fused(mults, c, h):
     assert record(f"sattn_wide_c{c}_h{h}", rel_err(from_rows(y, B, Fr, h, h), ref), LAYER_TOL) < LAYER_TOL
 
 
-@pytest.mark.parametrize("lvl,c,h", [(2, 512, 8), (2, 512, 5), (1, 256, 8), (1, 256, 3)])
+@pytest.mark.parametrize("lvl,c,h", [(2, 512, 8), (2, 512, 5), (1, 256, 8), (1, 256, 3), (1, 256, 16), (1, 256, 11)])
 def test_spatial_linear_attention_wide_fused(lvl, c, h):
     """SpatialLinearAttention at 256 / 512 channels as one launch (a workgroup per frame, a wave per head, the context in
-    registers), on full 8x8 frames and on frames of 25 and 9 positions, against the oracle."""
+    registers), on full 8x8 frames, on frames of 25 and 9 positions, and (256 channels) on frames of 256 and 121
+    positions, which the kernel sweeps twice with an online softmax over the positions, against the oracle."""
     kw = dict(dim=64, dim_mults=(1, 4, 8), channels=3)
     m = make_unet(salt=17, **kw)
     sd = {k: v.clone() for k, v in m.state_dict().items()}

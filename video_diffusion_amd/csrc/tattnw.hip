@@ -439,12 +439,235 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
     }
 }
 
+
+// SpatialLinearAttention over frames of MORE than 64 positions (the 16x16 level), still one launch and one workgroup per
+// frame: two sweeps over the frame in pairs of 32-row tiles.  Sweep A projects k and v and accumulates the context with
+// a running maximum per feature (online softmax over the positions); sweep B projects q, multiplies with the context
+// and runs the output projection per pair.  The rows are read and LayerNormed twice and the weight fragments are
+// streamed from L2 once per pair, which is still far less than the three launches it replaces.
+template <int C>
+__global__ __launch_bounds__(TW_HEADS * 64) void sla_wide_long_kernel(const TWArgs a) {
+    constexpr int KS = C / 16, CT = C / 32, NFRAG = 3 * KS + 2 * CT, SLICE = NFRAG * 512;
+    constexpr int XROW = C + 8, OROW = TW_HEADS * 32 + 8, NT = TW_NT;
+    constexpr int PPT = C / 64;      // 16-byte pieces per loader thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* xs = reinterpret_cast<__bf16*>(smem);                        // [NT * 32][XROW]
+    __bf16* os = xs + NT * 32 * XROW;                                    // [NT * 32][OROW]
+    float* xch = reinterpret_cast<float*>(os + NT * 32 * OROW);          // [heads][32]: per-feature factors, lane -> register order
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const long long frow0 = (long long)blockIdx.x * a.HW;
+    const int npairs = (a.HW + NT * 32 - 1) / (NT * 32);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const __bf16* wh = a.w + (long long)head * SLICE + lane * 8;
+
+    // rows p0 .. p0 + 63 of the frame -> LayerNorm -> xs (thread t: pieces (t & 7) + 8 i of row t >> 3)
+    auto load_rows = [&](int p0) {
+        const int rr = tid >> 3;
+        const bool ok = p0 + rr < a.HW;
+        const __bf16* src = a.x + (frow0 + (ok ? p0 + rr : 0)) * C;
+        bf16x8 pv[PPT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) v = *reinterpret_cast<const bf16x8*>(src + ((tid & 7) + 8 * i) * 8);
+            pv[i] = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        const float mean = s1 * (1.0f / C);
+        const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(((float)pv[i][e] - mean) * rstd);
+            *reinterpret_cast<bf16x8*>(xs + rr * XROW + ((tid & 7) + 8 * i) * 8) = o;
+        }
+    };
+    // a per-feature value held by lane d (both halves agree) -> the 16 values of this lane's context registers
+    // (register r is feature acc_row(r, half)); through this wave's 32 floats of LDS, no barrier needed
+    auto to_register_order = [&](float v, float (&out)[16]) {
+        float* xc = xch + head * 32;
+        if (half == 0) xc[l31] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(xc + 8 * u + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[4 * u + e] = q4[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- sweep A: context[d][e] = sum_n softmax_n(k)[n][d] v[n][e]
+    f32x16 ctx = zero, ctx1 = zero;
+    float m_run = -1e30f, l_run = 0.f;
+    for (int pi = 0; pi < npairs; ++pi) {
+        __syncthreads();
+        load_rows(pi * NT * 32);
+        bf16x8 wk[TW_PD], wv[TW_PD];
+#pragma unroll
+        for (int u = 0; u < TW_PD; ++u) {
+            wk[u] = *reinterpret_cast<const bf16x8*>(wh + (1 * KS + u) * 512);
+            wv[u] = *reinterpret_cast<const bf16x8*>(wh + (2 * KS + u) * 512);
+        }
+        __syncthreads();
+        f32x16 kk[NT], vv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { kk[t] = zero; vv[t] = zero; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int u = ks % TW_PD;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xs + (t * 32 + l31) * XROW + ks * 16 + 8 * half);
+                kk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, wk[u], kk[t], 0, 0, 0);
+                vv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, wv[u], vv[t], 0, 0, 0);
+            }
+            if (ks + TW_PD < KS) {
+                wk[u] = *reinterpret_cast<const bf16x8*>(wh + (1 * KS + ks + TW_PD) * 512);
+                wv[u] = *reinterpret_cast<const bf16x8*>(wh + (2 * KS + ks + TW_PD) * 512);
+            }
+        }
+        float tmax = -1e30f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (pi * NT * 32 + t * 32 + acc_row(r, half) >= a.HW) kk[t][r] = -1e30f;
+                tmax = fmaxf(tmax, kk[t][r]);
+            }
+        tmax = xhalf_max(tmax);
+        if (__any(tmax > m_run)) {      // some feature's maximum moved: rescale what has been accumulated
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            m_run = m_new;
+            l_run *= alpha;
+            float ar[16];
+            to_register_order(alpha, ar);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ctx[r] *= ar[r]; ctx1[r] *= ar[r]; }
+        }
+        const float mxl = m_run * LOG2E;
+        float lsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(kk[t][r], LOG2E, -mxl));
+                kk[t][r] = e;
+                lsum += e;
+            }
+        l_run += xhalf_add(lsum);
+        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(kk[0], 0), acc_frag(vv[0], 0), ctx, 0, 0, 0);
+        ctx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(kk[1], 0), acc_frag(vv[1], 0), ctx1, 0, 0, 0);
+        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(kk[0], 1), acc_frag(vv[0], 1), ctx, 0, 0, 0);
+        ctx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(kk[1], 1), acc_frag(vv[1], 1), ctx1, 0, 0, 0);
+    }
+    bf16x8 c0, c1;
+    {
+        float lr[16];
+        to_register_order(1.0f / l_run, lr);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctx[r] = (ctx[r] + ctx1[r]) * lr[r];
+        c0 = acc_frag(ctx, 0);
+        c1 = acc_frag(ctx, 1);
+    }
+    const int ee = l31 & 15, epos = (l31 >> 4) * 16 + ((ee >> 2) & 1) * 8 + (ee & 3) + 4 * (ee >> 3);
+
+    // ---- sweep B: q, out = q context, to_out + bias + residual, pair by pair
+    for (int pi = 0; pi < npairs; ++pi) {
+        __syncthreads();      // the previous pair's readers of xs / os are done
+        load_rows(pi * NT * 32);
+        bf16x8 wq[TW_PD];
+#pragma unroll
+        for (int u = 0; u < TW_PD; ++u) wq[u] = *reinterpret_cast<const bf16x8*>(wh + (0 * KS + u) * 512);
+        __syncthreads();
+        f32x16 qT[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qT[t] = zero;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int u = ks % TW_PD;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xs + (t * 32 + l31) * XROW + ks * 16 + 8 * half);
+                qT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[u], xb, qT[t], 0, 0, 0);
+            }
+            if (ks + TW_PD < KS) wq[u] = *reinterpret_cast<const bf16x8*>(wh + (0 * KS + ks + TW_PD) * 512);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float qm = qT[t][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) qm = fmaxf(qm, qT[t][r]);
+            qm = xhalf_max(qm);
+            const float qml = qm * LOG2E;
+            float qsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { qT[t][r] = __builtin_amdgcn_exp2f(fmaf(qT[t][r], LOG2E, -qml)); qsum += qT[t][r]; }
+            qsum = xhalf_add(qsum);
+            const float qinv = a.q_scale / qsum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qT[t][r] *= qinv;
+            f32x16 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(qT[t], 0), c0, zero, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(qT[t], 1), c1, o, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) os[(t * 32 + acc_row(r, half)) * OROW + head * 32 + epos] = f2bf(o[r]);
+        }
+        __syncthreads();
+        for (int ct = head; ct < CT; ct += TW_HEADS) {
+            f32x16 yacc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yacc[t] = zero;
+#pragma unroll
+            for (int hs = 0; hs < TW_HEADS * 2; ++hs) {
+                const int hd = hs >> 1, s = hs & 1;
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(a.w + (long long)hd * SLICE + (3 * KS + 2 * ct + s) * 512 + lane * 8);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 ob = *reinterpret_cast<const bf16x8*>(os + (t * 32 + l31) * OROW + hd * 32 + s * 16 + 8 * half);
+                    yacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, ob, yacc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int pos = pi * NT * 32 + t * 32 + l31;
+                if (pos < a.HW) {
+#pragma unroll
+                    for (int kl = 0; kl < 2; ++kl) {
+                        const int ch = (2 * ct + kl) * 16 + 8 * half;
+                        const long long off = (frow0 + pos) * C + ch;
+                        const bf16x8 xr = *reinterpret_cast<const bf16x8*>(a.x + off);
+                        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+                        if (a.b_out) {
+                            b0 = *reinterpret_cast<const f32x4*>(a.b_out + ch);
+                            b1 = *reinterpret_cast<const f32x4*>(a.b_out + ch + 4);
+                        }
+                        bf16x8 out;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) out[e] = f2bf(yacc[t][8 * kl + e] + (e < 4 ? b0[e & 3] : b1[e & 3]) + (float)xr[e]);
+                        *reinterpret_cast<bf16x8*>(a.y + off) = out;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }   // namespace
 
 static int frame_attention_wide(int mode, const void* x, void* y, const void* wpack, const float* b_out, int frames, int hw,
                                 int c, int heads, float q_scale, float eps, vdmi_stream stream_) {
     if (!x || !y || !wpack) return VDMI_E_ARG;
-    if (frames <= 0 || hw <= 0 || hw > TW_NT * 32 || (c != 256 && c != 512) || heads != TW_HEADS) return VDMI_E_SHAPE;
+    if (frames <= 0 || hw <= 0 || (c != 256 && c != 512) || heads != TW_HEADS) return VDMI_E_SHAPE;
+    if (hw > TW_NT * 32 && mode != 2) return VDMI_E_SHAPE;
     if (!aligned16(x) || !aligned16(y) || !aligned16(wpack)) return VDMI_E_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TWArgs a;
@@ -461,7 +684,21 @@ static int frame_attention_wide(int mode, const void* x, void* y, const void* wp
     a.ngroups = frames;
     a.q_scale = q_scale;
     a.eps = eps;
-    const size_t lds = (size_t)TW_NT * 32 * (c + 8) * 2 + (size_t)TW_NT * 32 * (TW_HEADS * 32 + 8) * 2;
+    const size_t lds = (size_t)TW_NT * 32 * (c + 8) * 2 + (size_t)TW_NT * 32 * (TW_HEADS * 32 + 8) * 2 + TW_HEADS * 32 * 4;
+    if (hw > TW_NT * 32) {      // linear attention over a larger frame: the two-sweep kernel
+#define VDMI_SL_CASE(C_)                                                                                          \
+    if (c == C_) {                                                                                                \
+        static std::atomic<uint64_t> attr_mask{0};                                                                \
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(sla_wide_long_kernel<C_>), attr_mask, 160 * 1024))     \
+            return VDMI_E_LAUNCH;                                                                                 \
+        hipLaunchKernelGGL((sla_wide_long_kernel<C_>), dim3(frames), dim3(TW_HEADS * 64), lds, stream, a);        \
+        VDMI_LAUNCH_CHECK();                                                                                      \
+        return VDMI_OK;                                                                                           \
+    }
+        VDMI_SL_CASE(256)      // (at 512 channels this kernel needs more registers than a wave has; those layers keep the three launches)
+#undef VDMI_SL_CASE
+        return VDMI_E_SHAPE;
+    }
 #define VDMI_SW_CASE(C_, MODE_)                                                                                         \
     if (c == C_ && mode == MODE_) {                                                                                     \
         static std::atomic<uint64_t> attr_mask{0};                                                                      \

@@ -414,7 +414,7 @@ class Plan:
                 x.data_ptr(), y.data_ptr(), wp.data_ptr(), wout.data_ptr(), bout.data_ptr(), ws.data_ptr(),
                 frames, hw, c, heads, sl["scale"], 1e-5, s), meta, name + ".fused")
             return y
-        if sl.get("fused_wide") is not None and hw <= 64:
+        if sl.get("fused_wide") is not None and (hw <= 64 or (c == 256 and SLA_WIDE_LONG)):
             y = self._buf(rows, c)
             wp, bout = sl["fused_wide"], sl["bout"]
             meta = {"kernel": "sla_fused_wide", "flops": 2.0 * rows * c * 4 * hid + 4.0 * rows * 32 * hid, "bytes": 4.0 * rows * c}
@@ -680,6 +680,8 @@ TATTN_WIDE_BELOW_HW = int(os.environ.get("VDMI_TATTN_WIDE_BELOW_HW", str(1 << 30
 # wide-layer convs that would launch fewer workgroups than this split their contraction (0: never)
 K_SPLIT_BELOW = int(os.environ.get("VDMI_K_SPLIT_BELOW", "256"))
 K_SPLIT_TARGET = int(os.environ.get("VDMI_K_SPLIT_TARGET", "320"))      # workgroups per launch the split aims at
+# SpatialLinearAttention at 256 channels on frames of more than 64 positions: the one-launch two-sweep kernel
+SLA_WIDE_LONG = os.environ.get("VDMI_SLA_WIDE_LONG", "1") != "0"
 BATCH_PARTS = int(os.environ.get("VDMI_BATCH_PARTS", "2"))
 BATCH_PARTS_MIN = int(os.environ.get("VDMI_BATCH_PARTS_MIN", "4"))     # smallest batch that is split
 
