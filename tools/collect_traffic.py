@@ -32,6 +32,11 @@ def klass(name):
         return f"tapgemm<epi={m.group(6)},bn={m.group(2)}>"
     if "wsconv64_kernel" in name:
         return "wsconv64"
+    m = re.search(r"tattn_wide_kernel<\d+, \w+, (\d)>", name)
+    if m:
+        return ("tattn_fused", "sattn_fused", "sla_fused_wide")[int(m.group(1))]
+    if "sla_wide_long_kernel" in name:
+        return "sla_fused_wide"
     for k in ("tattn_fused", "sla_pass1", "sla_pass2", "sla_fold", "rmsnorm_silu", "ddpm_step", "attn_core_lds",
               "xattn_core", "init_conv_mfma", "final_conv"):
         if k in name:
