@@ -175,6 +175,12 @@ class Plan:
         w_pack, bias = pk
         if w_pack.tile_bn == 64:
             return self._block_split(name, pk, srcs, h, w, gain, shift, bstride, res)
+        # a 128-channel block with a long contraction on a small image is one workgroup's latency long with the fused
+        # epilogue (a nominal 8 samples give 160 workgroups of 72 tap steps): the split form deals its contraction to twice
+        # the workgroups.  The packed weights serve both forms (same fragment order).
+        if (SPLIT_LONG_K and w_pack.n == 128 and (c0 + c1) >= SPLIT_LONG_K and 8 * self.F * h * w <= 128 * 200
+                and (res is None or res[0] != "conv")):
+            return self._block_split(name, pk, srcs, h, w, gain, shift, bstride, res)
         out = self._buf(frames * h * w, w_pack.n)
         a = self._base_args(frames, h, w, out, w_pack.n, EPI_NORM_SILU)
         _fill_pass(a.main, s0, c0, s1, c1, h, w, 1, TAPS_3x3, w_pack.data)
@@ -682,6 +688,7 @@ K_SPLIT_BELOW = int(os.environ.get("VDMI_K_SPLIT_BELOW", "256"))
 K_SPLIT_TARGET = int(os.environ.get("VDMI_K_SPLIT_TARGET", "320"))      # workgroups per launch the split aims at
 # SpatialLinearAttention at 256 channels on frames of more than 64 positions: the one-launch two-sweep kernel
 SLA_WIDE_LONG = os.environ.get("VDMI_SLA_WIDE_LONG", "1") != "0"
+SPLIT_LONG_K = int(os.environ.get("VDMI_SPLIT_LONG_K", "512"))      # input channels from which such a block takes the split form (0: never)
 BATCH_PARTS = int(os.environ.get("VDMI_BATCH_PARTS", "2"))
 BATCH_PARTS_MIN = int(os.environ.get("VDMI_BATCH_PARTS_MIN", "4"))     # smallest batch that is split
 
