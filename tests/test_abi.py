@@ -91,6 +91,42 @@ def test_bad_arguments_are_rejected_without_launching():
         _lib.check(-2, "probe")
 
 
+def test_fused_attention_and_threshold_entry_points_check_their_arguments():
+    """The wide fused attention family, the dynamic-threshold pair and the allocation-free GroupNorm refuse shapes and
+    pointers they do not serve before anything is launched (no GPU needed: the checks come first)."""
+    lib = _lib.lib()
+    buf = (C.c_uint8 * 4096)()
+    p = C.addressof(buf)
+    p = (p + 255) & ~255          # 256-byte aligned fake device pointer: never dereferenced on these paths
+    # temporal: channels, heads, frames
+    assert lib.vdmi_tattn_fused_wide(None, p, p, None, None, None, 1, 10, 64, 512, 8, 0.1, 1e-5, None, None) == -1
+    assert lib.vdmi_tattn_fused_wide(p, p, p, None, None, None, 1, 10, 64, 384, 8, 0.1, 1e-5, None, None) == -2
+    assert lib.vdmi_tattn_fused_wide(p, p, p, None, None, None, 1, 10, 64, 512, 4, 0.1, 1e-5, None, None) == -2
+    assert lib.vdmi_tattn_fused_wide(p, p, p, None, None, None, 1, 33, 64, 512, 8, 0.1, 1e-5, None, None) == -2
+    assert lib.vdmi_tattn_fused_wide(p, p + 2, p, None, None, None, 1, 10, 64, 512, 8, 0.1, 1e-5, None, None) == -3
+    # per-frame softmax attention: at most 64 positions
+    assert lib.vdmi_sattn_fused_wide(p, p, p, 4, 65, 512, 8, 0.1, 1e-5, None) == -2
+    assert lib.vdmi_sattn_fused_wide(p, p, p, 0, 64, 512, 8, 0.1, 1e-5, None) == -2
+    assert lib.vdmi_sattn_fused_wide(p, None, p, 4, 64, 512, 8, 0.1, 1e-5, None) == -1
+    # linear attention: larger frames only at 256 channels
+    assert lib.vdmi_sla_fused_wide(p, p, p, None, 4, 256, 512, 8, 0.1, 1e-5, None) == -2
+    assert lib.vdmi_sla_fused_wide(p, p, p, None, 4, 64, 128, 8, 0.1, 1e-5, None) == -2
+    assert lib.vdmi_sla_fused_wide(p, p, p, p + 4, 4, 64, 256, 8, 0.1, 1e-5, None) == -3
+    # dynamic threshold: percentile range, sample size (float32 ranks), noise source of the step
+    coefs = _lib.DdpmCoefs()
+    for f in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2",
+              "posterior_log_variance_clipped"):
+        setattr(coefs, f, p)
+    assert lib.vdmi_dynamic_threshold(p, p, p, C.byref(coefs), p, 2, 100, 1.5, None) == -1
+    assert lib.vdmi_dynamic_threshold(p, p, p, C.byref(coefs), p, 2, 1 << 24, 0.9, None) == -2
+    assert lib.vdmi_dynamic_threshold(p, p, p, C.byref(coefs), None, 2, 100, 0.9, None) == -1
+    assert lib.vdmi_ddpm_step_thres(p, p, None, p, C.byref(coefs), p, p, 2, 100, None, None) == -1      # no noise source
+    assert lib.vdmi_ddpm_step_thres(p, p, p, p, C.byref(coefs), p, p, 2, 100, p, None) == -1            # two noise sources
+    assert lib.vdmi_ddpm_step_thres(p, p, p, p, C.byref(coefs), None, p, 2, 100, None, None) == -1      # no thresholds
+    # allocation-free GroupNorm: inputs beyond the static scratch
+    assert lib.vdmi_groupnorm_silu_noalloc(p, p, 64, 1 << 22, 2048, 32, p, p, 1e-5, None) == -6
+
+
 def test_batch_split_policy():
     """Host logic of the two-stream forward: which batches are run as sub-batches, and the launch flags of a plan."""
     from video_diffusion_amd import engine
