@@ -420,7 +420,8 @@ class Plan:
                 x.data_ptr(), y.data_ptr(), wp.data_ptr(), wout.data_ptr(), bout.data_ptr(), ws.data_ptr(),
                 frames, hw, c, heads, sl["scale"], 1e-5, s), meta, name + ".fused")
             return y
-        if sl.get("fused_wide") is not None and (hw <= 64 or (c == 256 and SLA_WIDE_LONG)):
+        # (the two-sweep form walks a frame serially in one workgroup: beyond 16x16 the three launches are faster)
+        if sl.get("fused_wide") is not None and (hw <= 64 or (c == 256 and SLA_WIDE_LONG and hw <= 256)):
             y = self._buf(rows, c)
             wp, bout = sl["fused_wide"], sl["bout"]
             meta = {"kernel": "sla_fused_wide", "flops": 2.0 * rows * c * 4 * hid + 4.0 * rows * 32 * hid, "bytes": 4.0 * rows * c}
