@@ -1,6 +1,7 @@
 // Small kernels of the denoising path for gfx950: init conv, final 1x1 conv, time/condition
 // embedding, per-block scale/shift tables and the fused DDPM posterior step.
 #include "vdmi_common.h"
+#include <cstdlib>
 #include <mutex>
 
 namespace {
@@ -547,12 +548,14 @@ extern "C" int vdmi_init_conv(const float* x, const float* w, const float* bias,
         const int nks = (cin * ksize * ksize + 15) / 16, ct = cout / 32;
         const size_t mlds = (size_t)2 * ct * nks * 1024 + (size_t)nks * 64 + (size_t)cin * pdim * pdim * 4;
         if (mlds <= 160 * 1024) {
+            // tiles a workgroup walks (it converts the weights once, then stages patch after patch, serially)
+            static const int IC_TPW = [] { const char* e = std::getenv("VDMI_IC_TPW"); const int v = e ? std::atoi(e) : 2; return v < 1 ? 1 : v; }();      // 36 us at 4, 27 at 2, 29 at 1 (8 videos of 10 x 64 x 64)
 #define VDMI_IC_CASE(CT_)                                                                                    \
     if (ct == CT_) {                                                                                         \
         static std::atomic<uint64_t> attr_mask{0};                                                           \
         if (vdmi_set_max_lds(reinterpret_cast<const void*>(init_conv_mfma_kernel<CT_>), attr_mask, 160 * 1024)) \
             return VDMI_E_LAUNCH;                                                                            \
-        hipLaunchKernelGGL(init_conv_mfma_kernel<CT_>, dim3((tile_grid.x + 3) / 4, tile_grid.y), dim3(256), mlds, \
+        hipLaunchKernelGGL(init_conv_mfma_kernel<CT_>, dim3((tile_grid.x + IC_TPW - 1) / IC_TPW, tile_grid.y), dim3(256), mlds, \
                            static_cast<hipStream_t>(stream), x, w, bias, static_cast<__bf16*>(out), cin, f,  \
                            h, wd, ksize, nks);                                                               \
         VDMI_LAUNCH_CHECK();                                                                                 \
