@@ -388,6 +388,51 @@ int vdmi_ddpm_step_thres(const float* x, const float* eps, const float* z, const
                          const vdmi_ddpm_coefs* coefs, const float* thres, float* out, int b, int64_t per_sample,
                          const uint64_t* rng_state, vdmi_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward pieces of ResnetBlock (the gradients torch autograd derives for vdp.py:391-452 when the
+ * reference's Trainer calls loss.backward(), vdp.py:1451).  Activations and their gradients are
+ * channels-last bf16 rows as everywhere else; parameter gradients are float32 and are ACCUMULATED
+ * (the caller zeroes them), in the layout of the reference's parameters.
+ * ------------------------------------------------------------------------------------------ */
+
+/* vdmi_pack_taps on the device (same output, bit for bit, for transposed = 0): w float [n][cin0+cin1][ntaps] in
+ * device memory.  transposed = 1 packs the weight set of the convolution's input gradient instead: w is then the
+ * forward weight float [cin0+cin1][n][ntaps] (its OUTPUT channels are this pass's contraction axis) and the taps
+ * are taken in reverse order, so that with the same (dy, dx) table
+ *   dx[p][n'] = sum_{tap, k} w[k][n'][ntaps-1-tap] * dyout[p + (dy,dx)_tap][k]
+ * is the gradient of a stride-1 "same" convolution whose tap table is point-symmetric (the (1,3,3) and 1x1
+ * convolutions of ResnetBlock). */
+int vdmi_pack_taps_device(const float* w, int n, int npad, int cin0, int cin1, int ntaps, int bkc, int transposed,
+                          void* out, vdmi_stream stream);
+
+/* rows bf16 [nf*hw][ld], channel window [c_off, c_off + c)  ->  out bf16 [c][hw][nfpad], nfpad = nf rounded up to a
+ * multiple of 16, frames beyond nf zero: the operand layout of vdmi_conv_wgrad (the frame is the fast contraction
+ * index, so a tap shift never breaks a 16-byte fragment).  out holds vdmi_rows_transpose_elems() elements. */
+size_t vdmi_rows_transpose_elems(int c, int nf, int64_t hw);                              /* HOST */
+int vdmi_rows_transpose(const void* rows, int ld, int c_off, int c, int nf, int64_t hw, void* out, vdmi_stream stream);
+
+/* Weight gradient of a stride-1 (1,k,k) convolution (torch's conv3d weight gradient, vdp.py:415, 439):
+ *   dw[co][cin_off + ci][tap] += sum over frames f and pixels p of dy[f][p][co] * x[f][p + (dy,dx)_tap][ci]
+ * (zero outside the image).  xT: vdmi_rows_transpose of the input rows (cin channels), dyT: of the output-gradient
+ * rows (cout channels), both over nf frames of h x w pixels; dw float [cout][cin_total][ntaps]; ntaps 1 or 9.
+ * The sums are accumulated with floating-point atomics: the last bits depend on the order of arrival. */
+int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int cin, int cout, int cin_total, int cin_off,
+                    int nf, int h, int w, int ntaps, const int8_t* dy, const int8_t* dx, vdmi_stream stream);
+
+/* Backward of the tail of Block.forward (vdp.py:391-398, 421-427):
+ *   h = SiLU( F.normalize(y, dim=channels) * sqrt(c) * gamma * (scale[b] + 1) + shift[b] )
+ * y: the convolution's output rows [batch*rows_per_batch][ldy] (what the forward normalised), dh: gradient of h;
+ * writes dy (gradient of y) and accumulates dgamma [c], dbias [c] (= column sums of dy, the convolution's bias
+ * gradient; may be NULL), dscale / dshift [batch][c] (NULL when scale / shift are NULL: a block without a time
+ * embedding).  scale / shift: float [batch][sstride].  c: a power of two in 64..2048. */
+int vdmi_rmsnorm_silu_bwd(const void* y, int ldy, const void* dh, int ldh, void* dy, int lddy, int batch,
+                          int64_t rows_per_batch, int c, const float* gamma, const float* scale, const float* shift,
+                          int64_t sstride, float norm_scale, float* dgamma, float* dbias, float* dscale, float* dshift,
+                          vdmi_stream stream);
+
+/* out[ch] += sum over rows of x[row][ch]  (bias gradient of res_conv, vdp.py:439); x bf16 [rows][ld], c <= 2048. */
+int vdmi_colsum(const void* x, int ld, int64_t rows, int c, float* out, vdmi_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,14 @@ _SIGNATURES = {
                                          C.c_int64, C.c_float, C.c_void_p]),
     "vdmi_ddpm_step_thres": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vdmi_pack_taps_device": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
+    "vdmi_rows_transpose_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int64]),
+    "vdmi_rows_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vdmi_conv_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdmi_rmsnorm_silu_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdmi_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,6 +1,6 @@
 """Differentiable execution of Unet3D for training.
 
-The HIP kernels are forward-only.  The reference trains through PyTorch autograd (its Trainer,
+Apart from ResnetBlock (train_hip.py, opt-in) the HIP kernels are forward-only.  The reference trains through PyTorch autograd (its Trainer,
 video_diffusion_pytorch/video_diffusion_pytorch.py:1414-1453, calls loss.backward() on torch ops); this module
 runs the same arithmetic as torch ops over the module's own parameters so that `loss.backward()`, the optimizer
 and DistributedDataParallel work unchanged.  It is never used for sampling: `Unet3D.forward` only comes here
@@ -41,8 +41,14 @@ def _block(blk, x, scale_shift=None):
     return F.silu(x)
 
 
+_HIP_RESNET = False     # set by unet_forward for the duration of one forward (train_backend == "hip-resnet")
+
+
 def _resnet(rb, x, temb):
     # vdp.py:429-452; the (3,1,1) temporal conv of version1diffusion.py:308,322 when the block has one
+    if _HIP_RESNET and getattr(rb, "temporal_conv", None) is None:
+        from .train_hip import resnet_block     # forward and backward on the HIP kernels
+        return resnet_block(rb, x, temb)
     ss = None
     if rb.mlp is not None:
         e = rb.mlp[1](F.silu(temb))
@@ -155,7 +161,19 @@ def _mask(shape, prob, device):
 
 def unet_forward(unet, x, time, cond=None, null_cond_prob=0., frame_cond_features=None, null_frame_cond_prob=0.,
                  focus_present_mask=None, prob_focus_present=0.):
-    """Unet3D.forward (vdp.py:756-831) as differentiable torch ops over `unet`'s parameters."""
+    """Unet3D.forward (vdp.py:756-831) as differentiable torch ops over `unet`'s parameters; with
+    `unet.train_backend == "hip-resnet"` the ResnetBlocks run forward and backward on the HIP kernels (train_hip.py)."""
+    global _HIP_RESNET
+    prev, _HIP_RESNET = _HIP_RESNET, getattr(unet, "train_backend", None) == "hip-resnet"
+    try:
+        return _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null_frame_cond_prob,
+                             focus_present_mask, prob_focus_present)
+    finally:
+        _HIP_RESNET = prev
+
+
+def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null_frame_cond_prob, focus_present_mask,
+                  prob_focus_present):
     batch, device = x.shape[0], x.device
     focus = focus_present_mask if focus_present_mask is not None else _mask((batch,), prob_focus_present, device)
     focus = focus.to(device=device, dtype=torch.bool)

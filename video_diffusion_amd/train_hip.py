@@ -1,0 +1,216 @@
+"""ResnetBlock forward AND backward on the HIP kernels, as a torch.autograd.Function.
+
+The reference trains through PyTorch autograd (video_diffusion_pytorch/video_diffusion_pytorch.py:1451,
+`loss.backward()` over the torch ops of ResnetBlock, vdp.py:391-452).  With `unet.train_backend = "hip-resnet"` the
+differentiable forward of autograd.py hands every ResnetBlock (where most of a training step's arithmetic is: two
+(1,3,3) convolutions and a 1x1) to this module; the attention layers, resampling convolutions and embeddings stay
+torch ops.  Arithmetic: bf16 activations and activation gradients, fp32 accumulation, fp32 parameter gradients.
+
+  forward   conv (vdmi_tapgemm, PLAIN) -> y1;  vdmi_rmsnorm_silu -> h1;  conv -> y2;  vdmi_rmsnorm_silu (+ residual)
+  backward  vdmi_rmsnorm_silu_bwd  (dy, dgamma, dbias, dscale, dshift)
+            vdmi_tapgemm over dy with the transposed, tap-reversed weights (vdmi_pack_taps_device)   -> input gradient
+            vdmi_rows_transpose + vdmi_conv_wgrad                                                    -> weight gradient
+
+There is no fallback: a shape the kernels do not take raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import EPI_PLAIN, TapGemmArgs, check
+
+_TAPS_3x3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+_TAPS_1x1 = [(0, 0)]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def to_rows(x: torch.Tensor) -> torch.Tensor:
+    """(B, C, F, H, W) float -> channels-last bf16 rows [B*F*H*W][C]."""
+    return x.permute(0, 2, 3, 4, 1).reshape(-1, x.shape[1]).to(torch.bfloat16).contiguous()
+
+
+def from_rows(r: torch.Tensor, b: int, f: int, h: int, w: int) -> torch.Tensor:
+    return r.view(b, f, h, w, r.shape[1]).permute(0, 4, 1, 2, 3).float()
+
+
+class DevPack:
+    """A weight set in the tap-GEMM's fragment order, packed on the device (weights change every optimizer step)."""
+
+    def __init__(self, weight: torch.Tensor, transposed: bool):
+        # weight: a Conv3d weight (cout, cin, 1, kh, kw).  transposed: the set of the input-gradient pass
+        cout, cin = weight.shape[0], weight.shape[1]
+        ntaps = weight.shape[2] * weight.shape[3] * weight.shape[4]
+        w3 = weight.detach().reshape(cout, cin, ntaps).to(torch.float32).contiguous()
+        self.n, self.k = (cin, cout) if transposed else (cout, cin)
+        self.ntaps = ntaps
+        self.tile_bn = 64 if (self.n >= 256 and self.n % 64 == 0) else 0
+        if self.tile_bn == 64:
+            self.bn, self.bkc = 64, 64
+        else:
+            bn, bkc = C.c_int(), C.c_int()
+            check(_lib.lib().vdmi_tapgemm_tile(EPI_PLAIN, self.n, C.byref(bn), C.byref(bkc)), "vdmi_tapgemm_tile")
+            self.bn, self.bkc = bn.value, bkc.value
+        self.npad = (self.n + self.bn - 1) // self.bn * self.bn
+        lib = _lib.lib()
+        elems = lib.vdmi_pack_taps_elems(self.n, self.npad, self.k, 0, ntaps, self.bkc)
+        self.data = torch.empty(elems, dtype=torch.bfloat16, device=weight.device)
+        check(lib.vdmi_pack_taps_device(w3.data_ptr(), self.n, self.npad, self.k, 0, ntaps, self.bkc,
+                                        1 if transposed else 0, self.data.data_ptr(), _stream()), "vdmi_pack_taps_device")
+        self._keep = w3
+
+
+def conv_rows(src: torch.Tensor, pack: DevPack, bias, frames: int, fpb: int, h: int, w: int, residual=None) -> torch.Tensor:
+    """Stride-1 'same' convolution of channels-last rows through vdmi_tapgemm (PLAIN epilogue, + bias, + residual rows)."""
+    assert src.shape[1] == pack.k and src.dtype == torch.bfloat16 and src.is_contiguous()
+    out = torch.empty(frames * h * w, pack.n, device=src.device, dtype=torch.bfloat16)
+    a = TapGemmArgs()
+    a.frames, a.frames_per_batch = frames, fpb
+    a.grid_h, a.grid_w, a.out_h, a.out_w = h, w, h, w
+    a.out_mul = 1
+    a.out, a.ldo, a.n, a.epilogue = out.data_ptr(), pack.n, pack.n, EPI_PLAIN
+    taps = _TAPS_3x3 if pack.ntaps == 9 else _TAPS_1x1
+    p = a.main
+    p.src0, p.c0, p.c1 = src.data_ptr(), pack.k, 0
+    p.in_h, p.in_w, p.stride, p.ntaps = h, w, 1, len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        p.dy[i], p.dx[i] = dy, dx
+    p.w = pack.data.data_ptr()
+    a.bias = None if bias is None else bias.data_ptr()
+    a.tile_bn = pack.tile_bn
+    if residual is not None:
+        a.has_res, a.res_identity, a.ld_res = 2, residual.data_ptr(), residual.shape[1]
+    check(_lib.lib().vdmi_tapgemm(C.byref(a), _stream()), "vdmi_tapgemm")
+    return out
+
+
+def rmsnorm_silu_rows(y, gain, shift, bstride, rows_per_batch, residual=None):
+    rows, c = y.shape
+    out = torch.empty_like(y)
+    check(_lib.lib().vdmi_rmsnorm_silu(
+        y.data_ptr(), c, out.data_ptr(), c, rows, c, gain.data_ptr(), bstride,
+        None if shift is None else shift.data_ptr(), bstride, rows_per_batch, float(c) ** 0.5,
+        None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[1], _stream()),
+        "vdmi_rmsnorm_silu")
+    return out
+
+
+def rows_transposed(rows: torch.Tensor, nf: int, hw: int) -> torch.Tensor:
+    c = rows.shape[1]
+    lib = _lib.lib()
+    out = torch.empty(lib.vdmi_rows_transpose_elems(c, nf, hw), device=rows.device, dtype=torch.bfloat16)
+    check(lib.vdmi_rows_transpose(rows.data_ptr(), c, 0, c, nf, hw, out.data_ptr(), _stream()), "vdmi_rows_transpose")
+    return out
+
+
+def conv_wgrad(x_t: torch.Tensor, dy_t: torch.Tensor, cin: int, cout: int, nf: int, h: int, w: int, ntaps: int) -> torch.Tensor:
+    """float32 (cout, cin, 1, k, k) weight gradient from the transposed operands."""
+    k = 3 if ntaps == 9 else 1
+    dw = torch.zeros(cout, cin, 1, k, k, device=x_t.device, dtype=torch.float32)
+    taps = _TAPS_3x3 if ntaps == 9 else _TAPS_1x1
+    dy = (C.c_int8 * ntaps)(*[t[0] for t in taps])
+    dx = (C.c_int8 * ntaps)(*[t[1] for t in taps])
+    check(_lib.lib().vdmi_conv_wgrad(x_t.data_ptr(), dy_t.data_ptr(), dw.data_ptr(), cin, cout, cin, 0, nf, h, w, ntaps,
+                                     dy, dx, _stream()), "vdmi_conv_wgrad")
+    return dw
+
+
+def rmsnorm_silu_bwd_rows(y, dh, gamma, scale, shift, batch, rows_per_batch, want_bias=True):
+    rows, c = y.shape
+    dev = y.device
+    dy = torch.empty_like(y)
+    dgamma = torch.zeros(c, device=dev, dtype=torch.float32)
+    dbias = torch.zeros(c, device=dev, dtype=torch.float32) if want_bias else None
+    dscale = torch.zeros(batch, c, device=dev, dtype=torch.float32) if scale is not None else None
+    dshift = torch.zeros(batch, c, device=dev, dtype=torch.float32) if scale is not None else None
+    ptr = lambda t: None if t is None else t.data_ptr()
+    check(_lib.lib().vdmi_rmsnorm_silu_bwd(
+        y.data_ptr(), c, dh.data_ptr(), dh.shape[1], dy.data_ptr(), c, batch, rows_per_batch, c, gamma.data_ptr(),
+        ptr(scale), ptr(shift), c, float(c) ** 0.5, dgamma.data_ptr(), ptr(dbias), ptr(dscale), ptr(dshift), _stream()),
+        "vdmi_rmsnorm_silu_bwd")
+    return dy, dgamma, dbias, dscale, dshift
+
+
+def colsum_rows(x: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros(x.shape[1], device=x.device, dtype=torch.float32)
+    check(_lib.lib().vdmi_colsum(x.data_ptr(), x.shape[1], x.shape[0], x.shape[1], out.data_ptr(), _stream()), "vdmi_colsum")
+    return out
+
+
+class ResnetBlockFn(torch.autograd.Function):
+    """ResnetBlock.forward (vdp.py:442-452) with its backward; x float (B, Cin, F, H, W) -> float (B, Cout, F, H, W).
+    scale / shift: float [B][Cout] (the chunks of the block's time MLP output) or None; wres / bres None = identity."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, scale, shift, w1, b1, g1, w2, b2, g2, wres, bres):
+        if not x.is_cuda:
+            raise _lib.VdmiError("the hip-resnet training backend needs CUDA (HIP) tensors; there is no CPU path")
+        b, cin, f, h, w = x.shape
+        cout = w1.shape[0]
+        frames, hw = b * f, h * w
+        xr = to_rows(x)
+        g1v, g2v = g1.detach().reshape(-1).float().contiguous(), g2.detach().reshape(-1).float().contiguous()
+        if scale is not None:
+            scale_c, shift_c = scale.detach().float().contiguous(), shift.detach().float().contiguous()
+            gain1, bstride = (g1v[None, :] * (scale_c + 1)).contiguous(), cout
+        else:
+            scale_c = shift_c = None
+            gain1, bstride = g1v, 0
+        y1 = conv_rows(xr, DevPack(w1, False), b1.detach().float().contiguous(), frames, f, h, w)
+        h1 = rmsnorm_silu_rows(y1, gain1, shift_c, bstride, f * hw)
+        y2 = conv_rows(h1, DevPack(w2, False), b2.detach().float().contiguous(), frames, f, h, w)
+        if wres is None:
+            out = rmsnorm_silu_rows(y2, g2v, None, 0, f * hw, residual=xr)
+        else:
+            h2 = rmsnorm_silu_rows(y2, g2v, None, 0, f * hw)
+            out = conv_rows(xr, DevPack(wres, False), bres.detach().float().contiguous(), frames, f, h, w, residual=h2)
+        ctx.save_for_backward(xr, y1, h1, y2, g1v, g2v, scale_c, shift_c, w1, w2, wres)
+        ctx.dims = (b, cin, cout, f, h, w)
+        return from_rows(out, b, f, h, w)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dout):
+        xr, y1, h1, y2, g1v, g2v, scale_c, shift_c, w1, w2, wres = ctx.saved_tensors
+        b, cin, cout, f, h, w = ctx.dims
+        frames, hw = b * f, h * w
+        do = to_rows(dout)
+        # block2: SiLU / RMSNorm, then the conv
+        dy2, dg2, db2, _, _ = rmsnorm_silu_bwd_rows(y2, do, g2v, None, None, b, f * hw)
+        dy2_t = rows_transposed(dy2, frames, hw)
+        dw2 = conv_wgrad(rows_transposed(h1, frames, hw), dy2_t, cout, cout, frames, h, w, 9)
+        dh1 = conv_rows(dy2, DevPack(w2, True), None, frames, f, h, w)
+        # block1
+        dy1, dg1, db1, dscale, dshift = rmsnorm_silu_bwd_rows(y1, dh1, g1v, scale_c, shift_c, b, f * hw)
+        x_t = rows_transposed(xr, frames, hw)
+        dw1 = conv_wgrad(x_t, rows_transposed(dy1, frames, hw), cin, cout, frames, h, w, 9)
+        # residual branch, then the input gradient: dgrad of conv1 + (res_conv's dgrad | the identity)
+        if wres is None:
+            dwres = dbres = None
+            dx_res = do
+        else:
+            dwres = conv_wgrad(x_t, rows_transposed(do, frames, hw), cin, cout, frames, h, w, 1)
+            dbres = colsum_rows(do)
+            dx_res = conv_rows(do, DevPack(wres, True), None, frames, f, h, w)
+        dx = conv_rows(dy1, DevPack(w1, True), None, frames, f, h, w, residual=dx_res)
+        return (from_rows(dx, b, f, h, w), dscale, dshift, dw1, db1, dg1.view(cout, 1, 1, 1), dw2, db2,
+                dg2.view(cout, 1, 1, 1), dwres, dbres)
+
+
+def resnet_block(rb, x: torch.Tensor, temb) -> torch.Tensor:
+    """autograd.py's `_resnet` on the HIP kernels (blocks without the variant's temporal convolution)."""
+    scale = shift = None
+    if rb.mlp is not None:
+        e = rb.mlp[1](F.silu(temb))
+        scale, shift = e.chunk(2, dim=1)
+    rc = rb.res_conv
+    wres, bres = (rc.weight, rc.bias) if isinstance(rc, torch.nn.Conv3d) else (None, None)
+    return ResnetBlockFn.apply(x, scale, shift, rb.block1.proj.weight, rb.block1.proj.bias, rb.block1.norm.gamma,
+                               rb.block2.proj.weight, rb.block2.proj.bias, rb.block2.norm.gamma, wres, bres)
