@@ -414,10 +414,20 @@ int vdmi_rows_transpose(const void* rows, int ld, int c_off, int c, int nf, int6
 /* Weight gradient of a stride-1 (1,k,k) convolution (torch's conv3d weight gradient, vdp.py:415, 439):
  *   dw[co][cin_off + ci][tap] += sum over frames f and pixels p of dy[f][p][co] * x[f][p + (dy,dx)_tap][ci]
  * (zero outside the image).  xT: vdmi_rows_transpose of the input rows (cin channels), dyT: of the output-gradient
- * rows (cout channels), both over nf frames of h x w pixels; dw float [cout][cin_total][ntaps]; ntaps 1 or 9.
- * The sums are accumulated with floating-point atomics: the last bits depend on the order of arrival. */
+ * rows (cout channels), both over nf frames of h x w pixels; dw float [cout][cin_total][ntaps]; ntaps 1, or 9 with
+ * the row-major tap table (ky - 1, kx - 1).  workspace: vdmi_conv_wgrad_workspace_bytes() bytes (partial tiles of
+ * the workgroups that share a (co, ci) tile, added by a second launch in a fixed order: results are repeatable). */
+size_t vdmi_conv_wgrad_workspace_bytes(int cin, int cout, int nf, int h, int w, int ntaps);   /* HOST */
 int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int cin, int cout, int cin_total, int cin_off,
-                    int nf, int h, int w, int ntaps, const int8_t* dy, const int8_t* dx, vdmi_stream stream);
+                    int nf, int h, int w, int ntaps, const int8_t* dy, const int8_t* dx, void* workspace,
+                    vdmi_stream stream);
+
+/* The same gradient for a (1,kh,kw) "same" convolution with few input channels (Unet3D.init_conv, vdp.py:644: 3 -> dim,
+ * 7 x 7): a column of the contraction is a (ci, ky, kx) triple, so no lane idles on padding channels.  kh, kw odd;
+ * dw float [cout][cin][kh][kw], ACCUMULATED; workspace: vdmi_conv_wgrad_gather_workspace_bytes() bytes. */
+size_t vdmi_conv_wgrad_gather_workspace_bytes(int cin, int cout, int nf, int h, int w, int kh, int kw);   /* HOST */
+int vdmi_conv_wgrad_gather(const void* xT, const void* dyT, float* dw, int cin, int cout, int nf, int h, int w,
+                           int kh, int kw, void* workspace, vdmi_stream stream);
 
 /* Backward of the tail of Block.forward (vdp.py:391-398, 421-427):
  *   h = SiLU( F.normalize(y, dim=channels) * sqrt(c) * gamma * (scale[b] + 1) + shift[b] )

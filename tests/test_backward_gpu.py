@@ -77,6 +77,46 @@ def test_conv_wgrad_vs_torch(nf, h, w, cin, cout, ntaps):
     assert err < 1e-3
 
 
+@pytest.mark.parametrize("b,f,h,w,cin,cout,k", [(1, 5, 16, 16, 3, 64, 7), (2, 10, 12, 9, 1, 32, 7), (1, 3, 8, 8, 4, 128, 3)])
+def test_init_conv_weight_gradient_vs_torch(b, f, h, w, cin, cout, k):
+    """init_conv (vdp.py:644) through InitConvFn: torch's forward, weight / bias gradient from vdmi_conv_wgrad_gather."""
+    from video_diffusion_amd import train_hip as T
+    torch.manual_seed(7)
+    conv = torch.nn.Conv3d(cin, cout, (1, k, k), padding=(0, k // 2, k // 2)).to(DEV)
+    x = torch.randn(b, cin, f, h, w, device=DEV)
+    dout = torch.randn(b, cout, f, h, w, device=DEV)
+    conv(x).backward(dout)
+    ref_w, ref_b = conv.weight.grad.clone(), conv.bias.grad.clone()
+    conv.weight.grad = conv.bias.grad = None
+    xr = x.clone().requires_grad_(True)
+    T.init_conv(conv, xr).backward(dout)
+    ref_x = torch.nn.grad.conv3d_input(x.shape, conv.weight, dout, padding=(0, k // 2, k // 2))
+    tag = f"initconv.{cin}to{cout}.k{k}"
+    assert record(tag + ".dw", rel_err(conv.weight.grad, ref_w), 1e-2) < 1e-2        # operands rounded to bf16
+    assert record(tag + ".db", rel_err(conv.bias.grad, ref_b), 1e-5) < 1e-5
+    assert rel_err(xr.grad, ref_x) < 1e-5
+
+
+def test_pointwise_conv_vs_torch():
+    """final_conv[1] (vdp.py:728) through PointwiseConvFn against torch's Conv3d, forward and all three gradients."""
+    from video_diffusion_amd import train_hip as T
+    torch.manual_seed(8)
+    conv = torch.nn.Conv3d(64, 3, 1).to(DEV)
+    x = torch.randn(2, 64, 3, 16, 16, device=DEV)
+    dout = torch.randn(2, 3, 3, 16, 16, device=DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = conv(xa)
+    ya.backward(dout)
+    ref = (ya.detach(), xa.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    conv.weight.grad = conv.bias.grad = None
+    xb = x.clone().requires_grad_(True)
+    yb = T.pointwise_conv(conv, xb)
+    yb.backward(dout)
+    assert rel_err(yb.detach(), ref[0]) < 1e-5 and rel_err(xb.grad, ref[1]) < 1e-5
+    assert record("pointwise.dw", rel_err(conv.weight.grad, ref[2]), 1e-2) < 1e-2          # operands rounded to bf16
+    assert rel_err(conv.bias.grad, ref[3]) < 1e-5
+
+
 def _norm_ref(y, gamma, scale, shift):
     n = F.normalize(y, dim=1) * (y.shape[1] ** 0.5) * gamma
     if scale is not None:

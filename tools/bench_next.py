@@ -12,6 +12,9 @@ Workloads (random-init weights, synthetic inputs):
   textcfg    Unet3D(dim=128, dim_mults=(1,2,4,8), channels=3, cond_dim=768) on (--cfg-batch, 3, 16, 64, 64) with
              classifier-free guidance cond_scale=2: one step = one pass over the doubled batch (rows B.. take the
              null embedding) + guidance + posterior step, replayed as a HIP graph; with its roofline block.
+  train      Unet3D(dim=128, dim_mults=(1,2,4,8), channels=3) on (--train-batch, 3, 16, 128, 128): one p_losses
+             forward + backward (L1 loss on the predicted noise), with the all-torch backend ("torch-autograd", fp32 and
+             under bf16 autocast) and with the ResnetBlocks forward + backward on the HIP kernels ("hip-resnet").
 """
 import argparse
 import json
@@ -113,8 +116,64 @@ def text_cfg(args, dev):
     }), flush=True)
 
 
+def train_step(args, dev):
+    """configs[4] shape: loss forward + backward of the denoiser (reference vdp.py:1146-1161, 1451), per backend."""
+    import torch.nn.functional as F
+    from video_diffusion_amd import Unet3D
+    torch.manual_seed(0)
+    unet = Unet3D(dim=128, dim_mults=(1, 2, 4, 8), channels=3).to(dev)
+    B = args.train_batch
+    x = torch.randn(B, 3, 16, args.train_size, args.train_size, device=dev)
+    noise = torch.randn_like(x)
+    t = torch.randint(0, 1000, (B,), device=dev)
+
+    def step(backend, amp):
+        unet.train_backend = backend
+        for p in unet.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            loss = F.l1_loss(unet(x, t).float(), noise)
+        loss.backward()
+        return loss
+
+    out = {"workload": f"training step: Unet3D(dim=128, channels=3) p_losses forward + backward on {tuple(x.shape)}, "
+                       "random-init weights, no optimizer step", "ms_per_step": {}, "loss": {}, "peak_mem_gib": {}}
+    runs = (("hip-resnet", "hip-resnet", False), ("hip-resnet + bf16 autocast of the torch layers", "hip-resnet", True),
+            ("torch-autograd bf16 autocast", "torch-autograd", True),
+            ("torch-autograd fp32", "torch-autograd", False))
+    if args.train_backends:
+        runs = tuple(r for r in runs if r[0].split()[0] in args.train_backends.split(","))
+    for name, backend, amp in runs:
+        torch.cuda.reset_peak_memory_stats()
+        try:
+            ms = timed(lambda: step(backend, amp), args.train_steps, warmup=1)
+            out["ms_per_step"][name] = round(ms, 2)
+            out["loss"][name] = round(float(step(backend, amp)), 5)
+            out["peak_mem_gib"][name] = round(torch.cuda.max_memory_allocated() / 2**30, 2)
+        except Exception as e:     # report, do not hide: a backend that cannot run this shape says why
+            out["ms_per_step"][name] = f"failed: {type(e).__name__}: {str(e)[:200]}"
+    unet.train_backend = None
+    if args.train_profile:
+        # kernel time of ONE more hip-resnet step (after warm-up), by kernel name, from the torch profiler
+        from torch.profiler import ProfilerActivity, profile
+        amp = args.train_profile == "amp"
+        step("hip-resnet", amp)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step("hip-resnet", amp)
+            torch.cuda.synchronize()
+        rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:40]
+        out["hip_resnet_step_kernels_ms"] = {e.key[:90]: [round(e.device_time_total / 1e3, 3), e.count] for e in rows}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--train-batch", type=int, default=1)
+    ap.add_argument("--train-size", type=int, default=128)
+    ap.add_argument("--train-steps", type=int, default=3)
+    ap.add_argument("--train-profile", default="", help="fp32 | amp: add per-kernel times of one hip-resnet step")
+    ap.add_argument("--train-backends", default="", help="comma list out of hip-resnet,torch-autograd (default: all)")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--latent", type=int, default=64)
@@ -134,6 +193,8 @@ def main():
 
     if want("textcfg"):
         text_cfg(args, dev)
+    if "train" in only:        # only on request: the all-torch backends take seconds per step
+        train_step(args, dev)
     if not (want("framecond") or want("vae")):
         return
 

@@ -137,7 +137,10 @@ _SIGNATURES = {
     "vdmi_pack_taps_device": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
     "vdmi_rows_transpose_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int64]),
     "vdmi_rows_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
-    "vdmi_conv_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdmi_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "vdmi_conv_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] * 4),
+    "vdmi_conv_wgrad_gather_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
+    "vdmi_conv_wgrad_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
     "vdmi_rmsnorm_silu_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64,
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

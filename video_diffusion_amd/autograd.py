@@ -181,7 +181,11 @@ def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null
         focus = None                                   # vdp.py:590: the mask is skipped when nothing is flagged
     bias = _pos_bias(unet, x.shape[2], device)
 
-    x = unet.init_conv(x)
+    if _HIP_RESNET and x.is_cuda:
+        from .train_hip import init_conv        # torch forward, weight gradient on the HIP kernels
+        x = init_conv(unet.init_conv, x)
+    else:
+        x = unet.init_conv(x)
     x = _temporal(unet.init_temporal_attn, x, bias)
     r = x
     half = unet.dim // 2
@@ -222,4 +226,8 @@ def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null
             x = _cross_attention(unet.frame_cross_attns_up[i], x, ctx)
         x = up(x)
     x = torch.cat((x, r), dim=1)
-    return unet.final_conv[1](_resnet(unet.final_conv[0], x, None))
+    x = _resnet(unet.final_conv[0], x, None)
+    if _HIP_RESNET and x.is_cuda:
+        from .train_hip import pointwise_conv   # weight gradient on the HIP kernels
+        return pointwise_conv(unet.final_conv[1], x)
+    return unet.final_conv[1](x)

@@ -9,8 +9,10 @@
 //   the contraction index is the slow one, and an MFMA operand wants 8 consecutive contraction values per lane.  The
 //   rows are therefore transposed once into [channel][pixel][frame] (vdmi_rows_transpose): the FRAME is the fast
 //   contraction index.  A tap moves (y, x) and never the frame, so the fragment of a shifted pixel is again 16
-//   aligned bytes - no halo staging, no unaligned reads, no LDS at all: each wave streams its fragments from L1/L2
-//   and keeps one 32 x 32 accumulator per tap.
+//   aligned bytes - no unaligned reads, and one 32 x 32 accumulator per tap.  The 1x1 form streams its fragments
+//   straight from L1/L2; the 3x3 form stages rows through LDS (see wgrad3x3_lds_kernel).  Workgroups split the
+//   pixels of a (co, ci) tile, write partial tiles and a second kernel adds them (floating-point atomics to the
+//   same few addresses from a thousand workgroups cost a millisecond per layer).
 //
 //   The RMSNorm / scale-shift / SiLU backward is a row kernel (two row reductions, per-channel sums by atomics).
 #include "vdmi_common.h"
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void rows_transpose_kernel(const __bf16* __res
 struct WgradArgs {
     const __bf16* xT;
     const __bf16* dyT;
-    float* dw;
+    float* part;                 // partial tiles [gridDim.z][tiles][NT][64][64]
     int cin, cout, cin_total, cin_off;
     int h, w, nfpad;
     long long units, per;        // (frame blocks of 16) * h * w, units per blockIdx.z
@@ -145,19 +147,242 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             x = nx; y = ny; p = np; fb = nfb;
         }
     }
-    // accumulator register r of this lane: row co_base + (r&3) + 8*(r>>2) + 4*half, column ci
-    const int co_base = (blockIdx.x * 2 + (wave & 1)) * 32;
-    if (ci_ok) {
+    // partial tile of this workgroup: [tap][64 rows][64 columns]; register r of this lane is row
+    // (r&3) + 8*(r>>2) + 4*half of the wave's 32, column l31
+    float* part = a.part + ((size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * (NT * 4096);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row < a.cout) {
-                float* dst = a.dw + ((size_t)row * a.cin_total + a.cin_off + ci) * NT;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) unsafeAtomicAdd(dst + t, acc[t][r]);
-            }
+        for (int r = 0; r < 16; ++r)
+            part[(t * 64 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + (wave >> 1) * 32 + l31] = acc[t][r];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad of a (1,kh,kw) convolution with few input channels (init_conv: 3 -> dim, 7 x 7; torch's weight gradient,
+// vdp.py:644).  A tap-per-accumulator kernel would idle 29 of 32 columns, so here a column IS a (ci, ky, kx) triple:
+// n = (ci * kh + ky) * kw + kx, exactly the flattened weight index, and each lane gathers the fragment of its own
+// shifted pixel.  Same partial-tile output as wgrad_kernel<1> over cin * kh * kw "channels".
+// ------------------------------------------------------------------------------------------------------------------
+struct WgradGatherArgs {
+    const __bf16* xT;
+    const __bf16* dyT;
+    float* part;
+    int cin, cout, kh, kw;
+    int h, w, nfpad;
+    long long units, per;
+};
+
+__global__ __launch_bounds__(256) void wgrad_gather_kernel(const WgradGatherArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int co = (blockIdx.x * 2 + (wave & 1)) * 32 + l31;
+    const int n = (blockIdx.y * 2 + (wave >> 1)) * 32 + l31;
+    const int hw = a.h * a.w, ntaps = a.kh * a.kw;
+    const bool co_ok = co < a.cout, n_ok = n < a.cin * ntaps;
+    const int ci = n_ok ? n / ntaps : 0, t = n_ok ? n - ci * ntaps : 0;
+    const int ody = t / a.kw - a.kh / 2, odx = t % a.kw - a.kw / 2;
+    const __bf16* ap = a.dyT + (long long)(co_ok ? co : 0) * hw * a.nfpad + 8 * half;
+    const __bf16* bp = a.xT + (long long)ci * hw * a.nfpad + 8 * half;
+    f32x16 acc0, acc1;      // even / odd units: neighbouring MFMAs never share an accumulator
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long u = (long long)blockIdx.z * a.per;
+    const long long u_end = u + a.per < a.units ? u + a.per : a.units;
+    if (u < u_end) {
+        int fb = (int)(u / hw), p = (int)(u - (long long)fb * hw);
+        int y = p / a.w, x = p - y * a.w;
+        auto load_set = [&](bf16x8& A, bf16x8& B, int fb_, int p_, int y_, int x_) {
+            A = co_ok ? *reinterpret_cast<const bf16x8*>(ap + (long long)p_ * a.nfpad + fb_ * 16) : zero8;
+            const int yy = y_ + ody, xx = x_ + odx;
+            const bool ok = n_ok && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
+            B = ok ? *reinterpret_cast<const bf16x8*>(bp + (long long)(yy * a.w + xx) * a.nfpad + fb_ * 16) : zero8;
+        };
+        auto advance = [&]() {
+            ++p; ++x;
+            if (x == a.w) { x = 0; ++y; }
+            if (p == hw) { p = 0; y = 0; ++fb; }
+        };
+        for (; u + 1 < u_end; u += 2) {
+            bf16x8 A0, B0, A1, B1;
+            load_set(A0, B0, fb, p, y, x);
+            advance();
+            load_set(A1, B1, fb, p, y, x);
+            advance();
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc1, 0, 0, 0);
+        }
+        if (u < u_end) {
+            bf16x8 A0, B0;
+            load_set(A0, B0, fb, p, y, x);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
         }
     }
+    float* part = a.part + ((size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        part[((wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + (wave >> 1) * 32 + l31] = acc0[r] + acc1[r];
+}
+
+// dw[co][cin_off + ci][t] += sum over the nz partial tiles of a (co, ci) tile (one thread per element: deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nz, int tx, int ty, int nt,
+                                                           float* __restrict__ dw, int cout, int cin, int cin_total,
+                                                           int cin_off) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per_z = (long long)tx * ty * nt * 4096;
+    if (e >= per_z) return;
+    const int cl = (int)(e & 63), rl = (int)((e >> 6) & 63);
+    const int t = (int)((e >> 12) % nt), tile = (int)((e >> 12) / nt);
+    const int bx = tile % tx, by = tile / tx;
+    const int co = bx * 64 + rl, ci = by * 64 + cl;
+    if (co >= cout || ci >= cin) return;
+    float sum = 0.f;
+    for (int z = 0; z < nz; ++z) sum += part[(size_t)z * per_z + e];
+    dw[((size_t)co * cin_total + cin_off + ci) * nt + t] += sum;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad of the (1,3,3) convolution, staged through LDS.  The streaming kernel above asks the memory pipeline for 64
+// scattered 16-byte pieces per fragment (one per channel: the channel stride is a whole image), ten times per pixel,
+// and spends its time there.  Here a workgroup walks down a column strip of XT pixels: per image row it copies the
+// input row below (64 channels x (XT + 2) pixels x 16 frames, 32 contiguous bytes per pixel and channel) into a ring of
+// three rows and the output-gradient row into a second buffer, both as coalesced 16-byte pieces, and the waves read
+// their fragments from LDS (channel pitch = an odd number of 16-byte slots: conflict-free).  A wave keeps the three
+// patch columns of the 3 x 3 window in registers and slides them along the row: three new fragment reads and one
+// gradient fragment per pixel feed nine MFMAs.  80 KB of LDS: two workgroups per CU cover each other's barriers.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WG_XT = 8;                                  // pixels per strip
+constexpr int WG_XPITCH = (WG_XT + 2) * 32 + 16;          // bytes per channel of an input row in LDS
+constexpr int WG_DPITCH = WG_XT * 32 + 16;
+constexpr int WG_LDS = 3 * 64 * WG_XPITCH + 64 * WG_DPITCH;
+
+struct Wgrad3Args {
+    const __bf16* xT;
+    const __bf16* dyT;
+    float* part;
+    int cin, cout, cin_total, cin_off;
+    int h, w, nfpad;
+    int strips, ysegs, yseg_rows;
+};
+
+__global__ __launch_bounds__(256) void wgrad3x3_lds_kernel(const Wgrad3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xl = smem;                              // [3 rows][64 ci][WG_XPITCH]
+    char* dl = smem + 3 * 64 * WG_XPITCH;         // [64 co][WG_DPITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+    int z = blockIdx.z;
+    const int yseg = z % a.ysegs; z /= a.ysegs;
+    const int strip = z % a.strips;
+    const int fb = z / a.strips;
+    const int x0 = strip * WG_XT;
+    const int y0 = yseg * a.yseg_rows, y1 = min(y0 + a.yseg_rows, a.h);
+    const long long hw = (long long)a.h * a.w;
+
+    // staging pieces: x row = 64 ci x (XT+2) px x 2 halves, dy row = 64 co x XT px x 2 halves (16 bytes each)
+    constexpr int XP = 64 * (WG_XT + 2) * 2, DP = 64 * WG_XT * 2, XN = (XP + 255) / 256, DN = DP / 256;
+    bf16x8 xv[XN], dv[DN];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_x = [&](int row) {       // input row `row` (may be outside the image: zeros)
+#pragma unroll
+        for (int k = 0; k < XN; ++k) {
+            const int i = tid + k * 256;
+            const int hf = i & 1, px = (i >> 1) % (WG_XT + 2), ch = i / (2 * (WG_XT + 2));
+            const int gx = x0 - 1 + px, gc = ci0 + ch;
+            bf16x8 v = zero8;
+            if (i < XP && row >= 0 && row < a.h && gx >= 0 && gx < a.w && gc < a.cin)
+                v = *reinterpret_cast<const bf16x8*>(a.xT + ((long long)gc * hw + (long long)row * a.w + gx) * a.nfpad + fb * 16 + hf * 8);
+            xv[k] = v;
+        }
+    };
+    auto store_x = [&](int row) {
+        char* dst = xl + ((row + 3) % 3) * 64 * WG_XPITCH;
+#pragma unroll
+        for (int k = 0; k < XN; ++k) {
+            const int i = tid + k * 256;
+            const int hf = i & 1, px = (i >> 1) % (WG_XT + 2), ch = i / (2 * (WG_XT + 2));
+            if (i < XP) *reinterpret_cast<bf16x8*>(dst + ch * WG_XPITCH + px * 32 + hf * 16) = xv[k];
+        }
+    };
+    auto load_d = [&](int row) {
+#pragma unroll
+        for (int k = 0; k < DN; ++k) {
+            const int i = tid + k * 256;
+            const int hf = i & 1, px = (i >> 1) % WG_XT, ch = i / (2 * WG_XT);
+            const int gx = x0 + px, gc = co0 + ch;
+            bf16x8 v = zero8;
+            if (row < a.h && gx < a.w && gc < a.cout)
+                v = *reinterpret_cast<const bf16x8*>(a.dyT + ((long long)gc * hw + (long long)row * a.w + gx) * a.nfpad + fb * 16 + hf * 8);
+            dv[k] = v;
+        }
+    };
+    auto store_d = [&]() {
+#pragma unroll
+        for (int k = 0; k < DN; ++k) {
+            const int i = tid + k * 256;
+            const int hf = i & 1, px = (i >> 1) % WG_XT, ch = i / (2 * WG_XT);
+            *reinterpret_cast<bf16x8*>(dl + ch * WG_DPITCH + px * 32 + hf * 16) = dv[k];
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // rows y0 - 1 and y0 of the input, then the pipeline: iteration y stores (x row y + 1, dy row y), which were
+    // requested during the previous iteration's products
+    load_x(y0 - 1);
+    store_x(y0 - 1);
+    load_x(y0);
+    store_x(y0);
+    load_x(y0 + 1);
+    load_d(y0);
+    const char* afrag = dl + (wm * 32 + l31) * WG_DPITCH + half * 16;
+    const int boff = (wn * 32 + l31) * WG_XPITCH + half * 16;
+    for (int y = y0; y < y1; ++y) {
+        store_x(y + 1);
+        store_d();
+        __syncthreads();
+        if (y + 1 < y1) {
+            load_x(y + 2);
+            load_d(y + 1);
+        }
+        const char* r0 = xl + ((y - 1 + 3) % 3) * 64 * WG_XPITCH + boff;
+        const char* r1 = xl + ((y + 3) % 3) * 64 * WG_XPITCH + boff;
+        const char* r2 = xl + ((y + 1 + 3) % 3) * 64 * WG_XPITCH + boff;
+        bf16x8 c0[3], c1[3], c2[3];
+        c0[0] = *reinterpret_cast<const bf16x8*>(r0);
+        c0[1] = *reinterpret_cast<const bf16x8*>(r1);
+        c0[2] = *reinterpret_cast<const bf16x8*>(r2);
+        c1[0] = *reinterpret_cast<const bf16x8*>(r0 + 32);
+        c1[1] = *reinterpret_cast<const bf16x8*>(r1 + 32);
+        c1[2] = *reinterpret_cast<const bf16x8*>(r2 + 32);
+#pragma unroll
+        for (int px = 0; px < WG_XT; ++px) {
+            c2[0] = *reinterpret_cast<const bf16x8*>(r0 + (px + 2) * 32);
+            c2[1] = *reinterpret_cast<const bf16x8*>(r1 + (px + 2) * 32);
+            c2[2] = *reinterpret_cast<const bf16x8*>(r2 + (px + 2) * 32);
+            const bf16x8 A = *reinterpret_cast<const bf16x8*>(afrag + px * 32);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, c0[r], acc[3 * r + 0], 0, 0, 0);
+                acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, c1[r], acc[3 * r + 1], 0, 0, 0);
+                acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, c2[r], acc[3 * r + 2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; }
+        }
+        __syncthreads();       // the next iteration overwrites the dy row and the oldest input row
+    }
+
+    float* part = a.part + ((size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * (9 * 4096);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            part[(t * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + wn * 32 + l31] = acc[t][r];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -344,35 +569,123 @@ extern "C" int vdmi_rows_transpose(const void* rows, int ld, int c_off, int c, i
     return VDMI_OK;
 }
 
-extern "C" int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int cin, int cout, int cin_total, int cin_off,
-                               int nf, int h, int w, int ntaps, const int8_t* dy, const int8_t* dx, vdmi_stream stream) {
-    if (!xT || !dyT || !dw || !dy || !dx) return VDMI_E_ARG;
-    if (cin <= 0 || cout <= 0 || cin_off < 0 || cin_off + cin > cin_total || nf <= 0 || h <= 0 || w <= 0)
-        return VDMI_E_SHAPE;
-    if (ntaps != 1 && ntaps != 9) return VDMI_E_SHAPE;
-    if (!aligned16(xT) || !aligned16(dyT)) return VDMI_E_ALIGN;
+namespace {
+// how a weight-gradient launch splits the contraction (a function of the shapes only: the same every call)
+struct WgradPlan {
+    int tx, ty, nfb, strips, ysegs, yseg_rows;
+    long long units, per, gz;
+};
+int wgrad_plan(int cin, int cout, int nf, int h, int w, int ntaps, WgradPlan* p) {
+    if (cin <= 0 || cout <= 0 || nf <= 0 || h <= 0 || w <= 0 || (ntaps != 1 && ntaps != 9)) return VDMI_E_SHAPE;
     if ((long long)h * w > 0x3fffffffLL) return VDMI_E_SHAPE;
-    WgradArgs a;
+    p->tx = (cout + 63) / 64;
+    p->ty = (cin + 63) / 64;
+    p->nfb = (nf + 15) / 16;
+    if (p->tx > 65535 || p->ty > 65535) return VDMI_E_SHAPE;
+    const long long tiles = (long long)p->tx * p->ty;
+    constexpr long long kTargetWgs = 768;       // ~3 per CU; every workgroup writes a 64 x 64 x taps partial tile
+    if (ntaps == 9) {
+        p->strips = (w + WG_XT - 1) / WG_XT;
+        const long long base = tiles * p->nfb * p->strips;
+        long long segs = (kTargetWgs + base - 1) / base;
+        if (segs > (h + 3) / 4) segs = (h + 3) / 4;      // a segment re-reads two halo rows: at least 4 rows each
+        if (segs < 1) segs = 1;
+        p->yseg_rows = (int)((h + segs - 1) / segs);
+        p->ysegs = (h + p->yseg_rows - 1) / p->yseg_rows;
+        p->gz = (long long)p->nfb * p->strips * p->ysegs;
+        p->units = p->per = 0;
+    } else {
+        p->strips = p->ysegs = p->yseg_rows = 0;
+        p->units = (long long)p->nfb * h * w;
+        long long split = (kTargetWgs + tiles - 1) / tiles;
+        if (split > p->units / 16) split = p->units / 16;
+        if (split < 1) split = 1;
+        p->per = (p->units + split - 1) / split;
+        p->gz = (p->units + p->per - 1) / p->per;
+    }
+    return p->gz > 65535 ? VDMI_E_SHAPE : VDMI_OK;
+}
+}   // namespace
+
+extern "C" size_t vdmi_conv_wgrad_workspace_bytes(int cin, int cout, int nf, int h, int w, int ntaps) {
+    WgradPlan p;
+    if (wgrad_plan(cin, cout, nf, h, w, ntaps, &p) != VDMI_OK) return 0;
+    return (size_t)p.gz * p.tx * p.ty * ntaps * 4096 * sizeof(float);
+}
+
+extern "C" int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int cin, int cout, int cin_total, int cin_off,
+                               int nf, int h, int w, int ntaps, const int8_t* dy, const int8_t* dx, void* workspace,
+                               vdmi_stream stream) {
+    if (!xT || !dyT || !dw || !dy || !dx || !workspace) return VDMI_E_ARG;
+    if (cin_off < 0 || cin_off + cin > cin_total) return VDMI_E_SHAPE;
+    WgradPlan p;
+    const int st = wgrad_plan(cin, cout, nf, h, w, ntaps, &p);
+    if (st != VDMI_OK) return st;
+    if (!aligned16(xT) || !aligned16(dyT) || !aligned16(workspace)) return VDMI_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    const dim3 grid((unsigned)p.tx, (unsigned)p.ty, (unsigned)p.gz);
+    if (ntaps == 9) {
+        // the LDS kernel slides a 3 x 3 window: the tap table must be the row-major (ky - 1, kx - 1)
+        for (int t = 0; t < 9; ++t)
+            if (dy[t] != t / 3 - 1 || dx[t] != t % 3 - 1) return VDMI_E_SHAPE;
+        Wgrad3Args g;
+        g.xT = static_cast<const __bf16*>(xT);
+        g.dyT = static_cast<const __bf16*>(dyT);
+        g.part = part;
+        g.cin = cin; g.cout = cout; g.cin_total = cin_total; g.cin_off = cin_off;
+        g.h = h; g.w = w; g.nfpad = p.nfb * 16;
+        g.strips = p.strips; g.ysegs = p.ysegs; g.yseg_rows = p.yseg_rows;
+        static std::atomic<uint64_t> attr_mask{0};
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(wgrad3x3_lds_kernel), attr_mask, WG_LDS)) return VDMI_E_LAUNCH;
+        hipLaunchKernelGGL(wgrad3x3_lds_kernel, grid, dim3(256), WG_LDS, s, g);
+    } else {
+        WgradArgs a;
+        a.xT = static_cast<const __bf16*>(xT);
+        a.dyT = static_cast<const __bf16*>(dyT);
+        a.part = part;
+        a.cin = cin; a.cout = cout; a.cin_total = cin_total; a.cin_off = cin_off;
+        a.h = h; a.w = w; a.nfpad = p.nfb * 16;
+        for (int t = 0; t < 9; ++t) { a.dy[t] = t < ntaps ? dy[t] : 0; a.dx[t] = t < ntaps ? dx[t] : 0; }
+        a.units = p.units;
+        a.per = p.per;
+        hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, s, a);
+    }
+    VDMI_LAUNCH_CHECK();
+    const long long elems = (long long)p.tx * p.ty * ntaps * 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, part, (int)p.gz, p.tx,
+                       p.ty, ntaps, dw, cout, cin, cin_total, cin_off);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" size_t vdmi_conv_wgrad_gather_workspace_bytes(int cin, int cout, int nf, int h, int w, int kh, int kw) {
+    if (kh <= 0 || kw <= 0 || cin <= 0 || (long long)cin * kh * kw > 65535) return 0;
+    return vdmi_conv_wgrad_workspace_bytes(cin * kh * kw, cout, nf, h, w, 1);
+}
+
+extern "C" int vdmi_conv_wgrad_gather(const void* xT, const void* dyT, float* dw, int cin, int cout, int nf, int h, int w,
+                                      int kh, int kw, void* workspace, vdmi_stream stream) {
+    if (!xT || !dyT || !dw || !workspace) return VDMI_E_ARG;
+    if (kh <= 0 || kw <= 0 || !(kh & 1) || !(kw & 1) || cin <= 0 || (long long)cin * kh * kw > 65535) return VDMI_E_SHAPE;
+    const int ncol = cin * kh * kw;
+    WgradPlan p;
+    const int st = wgrad_plan(ncol, cout, nf, h, w, 1, &p);
+    if (st != VDMI_OK) return st;
+    if (!aligned16(xT) || !aligned16(dyT) || !aligned16(workspace)) return VDMI_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WgradGatherArgs a;
     a.xT = static_cast<const __bf16*>(xT);
     a.dyT = static_cast<const __bf16*>(dyT);
-    a.dw = dw;
-    a.cin = cin; a.cout = cout; a.cin_total = cin_total; a.cin_off = cin_off;
-    a.h = h; a.w = w; a.nfpad = (nf + 15) / 16 * 16;
-    for (int t = 0; t < 9; ++t) { a.dy[t] = t < ntaps ? dy[t] : 0; a.dx[t] = t < ntaps ? dx[t] : 0; }
-    a.units = (long long)(a.nfpad / 16) * h * w;
-    const int tx = (cout + 63) / 64, ty = (cin + 63) / 64;
-    // enough workgroups to fill the device a few times over, each with at least 16 contraction steps
-    long long split = (1024 + (long long)tx * ty - 1) / ((long long)tx * ty);
-    if (split > a.units / 16) split = a.units / 16;
-    if (split < 1) split = 1;
-    if (split > 65535) split = 65535;
-    a.per = (a.units + split - 1) / split;
-    split = (a.units + a.per - 1) / a.per;
-    if (tx > 65535 || ty > 65535) return VDMI_E_SHAPE;
-    const dim3 grid((unsigned)tx, (unsigned)ty, (unsigned)split);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ntaps == 9) hipLaunchKernelGGL(wgrad_kernel<9>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, s, a);
+    a.part = static_cast<float*>(workspace);
+    a.cin = cin; a.cout = cout; a.kh = kh; a.kw = kw;
+    a.h = h; a.w = w; a.nfpad = p.nfb * 16;
+    a.units = p.units; a.per = p.per;
+    hipLaunchKernelGGL(wgrad_gather_kernel, dim3((unsigned)p.tx, (unsigned)p.ty, (unsigned)p.gz), dim3(256), 0, s, a);
+    VDMI_LAUNCH_CHECK();
+    const long long elems = (long long)p.tx * p.ty * 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, a.part, (int)p.gz, p.tx,
+                       p.ty, 1, dw, cout, ncol, ncol, 0);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
