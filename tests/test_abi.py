@@ -143,3 +143,36 @@ def test_batch_split_policy():
         engine.BATCH_PARTS = old
     c = engine._Call(lambda s: 0, None, "x", side=True)
     assert c.side and not c.join
+
+
+def test_backward_entry_points_reject_bad_arguments():
+    """Argument checks of the backward entry points (no GPU work: every call returns before a launch)."""
+    import ctypes as C
+    from video_diffusion_amd import _lib
+    lib = _lib.lib()
+    E_ARG, E_SHAPE, E_ALIGN = -1, -2, -3
+    assert lib.vdmi_pack_taps_device(None, 64, 64, 64, 0, 9, 64, 0, None, None) == E_ARG
+    assert lib.vdmi_pack_taps_device(16, 64, 48, 64, 0, 9, 64, 0, 16, None) == E_SHAPE          # npad < n
+    assert lib.vdmi_pack_taps_device(16, 64, 64, 64, 0, 9, 64, 0, 24, None) == E_ALIGN
+    assert lib.vdmi_rows_transpose_elems(64, 10, 100) == 64 * 100 * 16
+    assert lib.vdmi_rows_transpose(None, 64, 0, 64, 10, 100, None, None) == E_ARG
+    assert lib.vdmi_rows_transpose(16, 64, 0, 60, 10, 100, 16, None) == E_SHAPE                # c not a multiple of 8
+    assert lib.vdmi_rows_transpose(16, 64, 8, 64, 10, 100, 16, None) == E_SHAPE                # window past the row
+    taps = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+    dy = (C.c_int8 * 9)(*[t[0] for t in taps])
+    dx = (C.c_int8 * 9)(*[t[1] for t in taps])
+    assert lib.vdmi_conv_wgrad_workspace_bytes(64, 64, 10, 8, 8, 9) > 0
+    assert lib.vdmi_conv_wgrad_workspace_bytes(64, 64, 10, 8, 8, 4) == 0                        # 1 or 9 taps only
+    assert lib.vdmi_conv_wgrad(None, 16, 16, 64, 64, 64, 0, 10, 8, 8, 9, dy, dx, 16, None) == E_ARG
+    assert lib.vdmi_conv_wgrad(16, 16, 16, 64, 64, 64, 8, 10, 8, 8, 9, dy, dx, 16, None) == E_SHAPE   # window past cin_total
+    bad = (C.c_int8 * 9)(*[t[1] for t in taps])
+    assert lib.vdmi_conv_wgrad(16, 16, 16, 64, 64, 64, 0, 10, 8, 8, 9, bad, dx, 16, None) == E_SHAPE  # not the 3 x 3 table
+    assert lib.vdmi_conv_wgrad_gather(16, 16, 16, 3, 64, 10, 8, 8, 4, 4, 16, None) == E_SHAPE         # even kernel
+    assert lib.vdmi_rmsnorm_silu_bwd(None, 64, 16, 64, 16, 64, 1, 10, 64, None, None, None, 0, 8.0, None, None, None,
+                                     None, None) == E_ARG
+    assert lib.vdmi_rmsnorm_silu_bwd(16, 96, 16, 96, 16, 96, 1, 10, 96, 16, None, None, 0, 9.8, 16, None, None, None,
+                                     None) == E_SHAPE                                                   # c not a power of two
+    assert lib.vdmi_rmsnorm_silu_bwd(16, 64, 16, 64, 16, 64, 1, 10, 64, 16, 16, None, 64, 8.0, 16, None, None, None,
+                                     None) == E_ARG                                                     # scale without shift
+    assert lib.vdmi_colsum(None, 64, 10, 64, None, None) == E_ARG
+    assert lib.vdmi_colsum(16, 64, 10, 4096, 16, None) == E_SHAPE

@@ -230,6 +230,9 @@ class Trainer(object):
         self.results_folder = Path(results_folder)
         self.results_folder.mkdir(exist_ok=True, parents=True)
         self.reset_parameters()
+        # not a constructor argument (the reference's Trainer signature stays as it is): set the attribute, or the
+        # environment variable VDMI_TRAIN_BACKEND, before train()
+        self.train_backend = os.environ.get("VDMI_TRAIN_BACKEND", "torch-autograd")
 
     @property
     def device(self):
@@ -292,7 +295,9 @@ class Trainer(object):
         assert callable(log_fn)
         dev = self.device
         if hasattr(self.model.denoise_fn, "train_backend"):
-            self.model.denoise_fn.train_backend = "torch-autograd"
+            # "torch-autograd": every layer differentiates through torch ops; "hip-resnet": the ResnetBlocks (and the weight
+            # gradients of init_conv / final_conv) run forward and backward on the HIP kernels (train_hip.py)
+            self.model.denoise_fn.train_backend = self.train_backend
         loss_mod = _LossModule(self.model, self.null_frame_cond_prob)
         if self.distributed:
             loss_mod = nn.parallel.DistributedDataParallel(
