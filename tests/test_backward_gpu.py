@@ -195,6 +195,8 @@ def test_resnet_block_forward_backward_vs_torch_autograd(cin, cout, temb):
 
     out_ref, g_ref = run(A._resnet)
     out_hip, g_hip = run(T.resnet_block)
+    with torch.no_grad():       # the module called on its own, as a user of the reference's ResnetBlock would
+        assert torch.equal(rb(x, te) if te is not None else rb(x), out_hip)
     tag = f"resnet_bwd.{cin}to{cout}"
     assert record(tag + ".out", rel_err(out_hip, out_ref), 2e-2) < 2e-2
     assert set(g_hip) == set(g_ref)

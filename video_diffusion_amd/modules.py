@@ -124,6 +124,16 @@ class ResnetBlock(_HipOnly):
         self.block2 = Block(dim_out, dim_out)
         self.res_conv = nn.Conv3d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
 
+    def forward(self, x, time_emb=None):
+        """The block on its own (reference vdp.py:442-452), differentiable: forward and backward run on the HIP kernels
+        (train_hip.py).  x float (B, dim, F, H, W) on the GPU; channel widths powers of two from 64 to 2048."""
+        if exists(self.mlp):
+            assert exists(time_emb), 'time emb must be passed in'
+        if getattr(self, "temporal_conv", None) is not None:
+            return super().forward(x, time_emb)      # the variant's block runs only inside its Unet3D
+        from .train_hip import resnet_block
+        return resnet_block(self, x, time_emb if exists(self.mlp) else None)
+
 
 class SpatialLinearAttention(_HipOnly):
     def __init__(self, dim, heads=4, dim_head=32):

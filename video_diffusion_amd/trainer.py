@@ -207,7 +207,10 @@ class Trainer(object):
 
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.distributed = self.world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized()
+        # VDMI_DDP_SINGLE_RANK=1: wrap in DistributedDataParallel even with one rank (a one-GPU box can then exercise the
+        # bucketed RCCL all-reduce path)
+        self.distributed = ((self.world > 1 or os.environ.get("VDMI_DDP_SINGLE_RANK") == "1")
+                            and torch.distributed.is_available() and torch.distributed.is_initialized())
 
         self.ds = Dataset(folder, diffusion_model.image_size, channels=diffusion_model.channels,
                           num_frames=diffusion_model.num_frames, num_prev_frames=num_prev_frames)
