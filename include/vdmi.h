@@ -443,6 +443,34 @@ int vdmi_rmsnorm_silu_bwd(const void* y, int ldy, const void* dh, int ldh, void*
 /* out[ch] += sum over rows of x[row][ch]  (bias gradient of res_conv, vdp.py:439); x bf16 [rows][ld], c <= 2048. */
 int vdmi_colsum(const void* x, int ld, int64_t rows, int c, float* out, vdmi_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training kernels of the temporal attention layer, Residual(PreNorm(EinopsToAndFrom('b c f h w', 'b (h w) f c',
+ * Attention))) (vdp.py:380-389, 531-612, 636), forward and backward.  The projections are vdmi_tapgemm row GEMMs
+ * (weights from vdmi_pack_taps_device, weight gradients from vdmi_conv_wgrad); these are the pieces between them.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Channel LayerNorm without gamma (vdp.py:386-389; gamma is folded into to_qkv): xh = (x - mean) / sqrt(var + eps),
+ * biased variance; bf16 rows [rows][c], c a power of two in 64..2048.  Backward: from the layer's input rows x and the
+ * gradient of xh,  dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)) + add  (add: optional rows, e.g. the residual
+ * branch's gradient). */
+int vdmi_layernorm_rows(const void* x, void* xh, int64_t rows, int c, float eps, vdmi_stream stream);
+int vdmi_layernorm_rows_bwd(const void* x, const void* dxh, const void* add, void* dx, int64_t rows, int c, float eps,
+                            vdmi_stream stream);
+
+/* Attention over the f frames of every site (vdp.py:560-606 without the focus mask), heads of 32 features, on the RAW
+ * rows of to_qkv: qkv bf16 [b*f*hw][3*heads*32] (q | k | v, column = head*32 + feature; row = (b*f + frame)*hw + site).
+ * q * scale, half-split rotary on q and k (rot_cos / rot_sin: float [f][16] or NULL), + bias (float [heads][f][f],
+ * entry (query, key), or NULL), softmax over the keys, . v  ->  o bf16 [rows][heads*32], lse float [rows][heads]
+ * (log-sum-exp of each row's scores, kept for the backward).  f <= 32, f*heads <= 256; the backward keeps four
+ * f*heads x 32 float tiles and the bias-gradient table in LDS (VDMI_E_LDS beyond: f <= 24 at 8 heads).
+ * Backward: from qkv, o, lse and dout (gradient of o) the gradient of the raw qkv rows (dqkv, same layout) and of the
+ * bias (dbias float [heads][f][f], ACCUMULATED; may be NULL). */
+int vdmi_tattn_core_fwd(const void* qkv, void* o, float* lse, const float* bias, const float* rot_cos,
+                        const float* rot_sin, int b, int f, int hw, int heads, float scale, vdmi_stream stream);
+int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* dbias,
+                        const float* bias, const float* rot_cos, const float* rot_sin, int b, int f, int hw, int heads,
+                        float scale, vdmi_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

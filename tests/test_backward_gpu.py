@@ -228,6 +228,13 @@ def test_unet_backward_hip_resnet_vs_torch_autograd():
     l_hip, gx_hip, g_hip = run("hip-resnet")
     assert set(g_ref) == set(g_hip)
     assert record("unet_bwd.loss", abs(float(l_hip - l_ref)) / float(l_ref), 2e-2) < 2e-2
+    # ... and with the temporal attention layers on the HIP kernels too
+    l_all, gx_all, g_all = run("hip")
+    assert set(g_ref) == set(g_all)
+    assert record("unet_bwd_hip.loss", abs(float(l_all - l_ref)) / float(l_ref), 2e-2) < 2e-2
+    cat_ = lambda d: torch.cat([d[n].flatten() for n in sorted(d)])
+    assert record("unet_bwd_hip.all_param_grads", rel_err(cat_(g_all), cat_(g_ref)), 6e-2) < 6e-2
+    assert record("unet_bwd_hip.input_grad", rel_err(gx_all, gx_ref), 1.2e-1) < 1.2e-1
     # the loss is an L1: its gradient is a sign pattern, which flips wherever the bf16 forward moves a residual across
     # zero; the parameter gradients (sums over all positions) are the stable quantity
     cat = lambda d: torch.cat([d[n].flatten() for n in sorted(d)])
@@ -235,3 +242,135 @@ def test_unet_backward_hip_resnet_vs_torch_autograd():
     assert record("unet_bwd.input_grad", rel_err(gx_hip, gx_ref), 1e-1) < 1e-1
     worst = max((rel_err(g_hip[n], g_ref[n]), n) for n in g_ref if g_ref[n].norm() > 1e-6 * cat(g_ref).norm())
     record("unet_bwd.worst_param_grad", worst[0], None)
+
+
+@pytest.mark.parametrize("c,rows", [(64, 1000), (256, 333), (1024, 70)])
+def test_layernorm_rows_forward_backward_vs_torch(c, rows):
+    from video_diffusion_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    x = _bf(torch.randn(rows, c, generator=g) * 2 + 0.5).to(DEV)
+    dxh = _bf(torch.randn(rows, c, generator=g)).to(DEV)
+    add = _bf(torch.randn(rows, c, generator=g)).to(DEV)
+    xh, dx = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(lib.vdmi_layernorm_rows(x.data_ptr(), xh.data_ptr(), rows, c, 1e-5, None))
+    _lib.check(lib.vdmi_layernorm_rows_bwd(x.data_ptr(), dxh.data_ptr(), add.data_ptr(), dx.data_ptr(), rows, c, 1e-5, None))
+    xr = x.double().requires_grad_(True)
+    ref = (xr - xr.mean(1, keepdim=True)) / (xr.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()
+    ref.backward(dxh.double())
+    assert record(f"layernorm.c{c}.fwd", rel_err(xh.float().cpu(), ref.detach().cpu()), 5e-3) < 5e-3
+    assert record(f"layernorm.c{c}.bwd", rel_err(dx.float().cpu(), (xr.grad + add.double()).cpu()), 5e-3) < 5e-3
+
+
+def _attn_core_ref(qkv, bias, cos, sin, b, f, hw, heads, scale):
+    """Attention over frames on raw q, k, v rows (vdp.py:560-606), double precision torch ops."""
+    hid = heads * 32
+    t = qkv.view(b, f, hw, 3, heads, 32).permute(3, 0, 2, 4, 1, 5)            # [3][b][hw][heads][f][32]
+    q, k, v = t[0] * scale, t[1], t[2]
+
+    def rot(u):
+        if cos is None:
+            return u
+        c = torch.cat((cos, cos), -1).double()
+        s = torch.cat((sin, sin), -1).double()
+        u1, u2 = u.chunk(2, dim=-1)
+        return u * c + torch.cat((-u2, u1), -1) * s
+    sim = rot(q) @ rot(k).transpose(-1, -2)
+    if bias is not None:
+        sim = sim + bias
+    out = sim.softmax(-1) @ v                                                  # [b][hw][heads][f][32]
+    return out.permute(0, 3, 1, 2, 4).reshape(b * f * hw, hid)
+
+
+@pytest.mark.parametrize("b,f,hw,heads,rotary,with_bias", [(2, 10, 37, 8, True, True), (1, 16, 64, 8, True, True),
+                                                           (3, 5, 20, 4, False, False), (1, 24, 9, 8, True, True)])
+def test_tattn_core_forward_backward_vs_torch(b, f, hw, heads, rotary, with_bias):
+    from video_diffusion_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(10)
+    rows, hid = b * f * hw, heads * 32
+    qkv = _bf(torch.randn(rows, 3 * hid, generator=g)).to(DEV)
+    dout = _bf(torch.randn(rows, hid, generator=g)).to(DEV)
+    bias = (0.5 * torch.randn(heads, f, f, generator=g)).to(DEV) if with_bias else None
+    ang = torch.arange(f).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None, :]
+    cos, sin = (ang.cos().to(DEV).contiguous(), ang.sin().to(DEV).contiguous()) if rotary else (None, None)
+    scale = 32 ** -0.5
+    ptr = lambda t: None if t is None else t.data_ptr()
+    o = torch.empty(rows, hid, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(rows, heads, device=DEV)
+    _lib.check(lib.vdmi_tattn_core_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ptr(bias), ptr(cos), ptr(sin), b, f, hw,
+                                       heads, scale, None))
+    dqkv = torch.empty_like(qkv)
+    dbias = torch.zeros_like(bias) if with_bias else None
+    _lib.check(lib.vdmi_tattn_core_bwd(qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                       ptr(dbias), ptr(bias), ptr(cos), ptr(sin), b, f, hw, heads, scale, None))
+    qr = qkv.double().requires_grad_(True)
+    br = bias.double().requires_grad_(True) if with_bias else None
+    ref = _attn_core_ref(qr, br, cos, sin, b, f, hw, heads, scale)
+    ref.backward(dout.double())
+    tag = f"tattn_core.f{f}.h{heads}"
+    assert record(tag + ".o", rel_err(o.float().cpu(), ref.detach().cpu()), 5e-3) < 5e-3
+    assert record(tag + ".dqkv", rel_err(dqkv.float().cpu(), qr.grad.cpu()), 1e-2) < 1e-2
+    if with_bias:
+        assert record(tag + ".dbias", rel_err(dbias.cpu(), br.grad.cpu()), 5e-3) < 5e-3
+
+
+@pytest.mark.parametrize("c,f,h,w", [(64, 10, 12, 12), (256, 4, 8, 8)])
+def test_temporal_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w):
+    """The whole layer (vdp.py:636) through TemporalAttnFn against the torch ops of autograd.py: output, input gradient
+    and the gradients of gamma, to_qkv, to_out and the relative-position bias."""
+    from video_diffusion_amd import autograd as A, train_hip as T
+    from video_diffusion_amd.modules import Attention, EinopsToAndFrom, PreNorm, Residual, RotaryEmbedding
+    torch.manual_seed(12)
+    rot = RotaryEmbedding(32)
+    res = Residual(PreNorm(c, EinopsToAndFrom('b c f h w', 'b (h w) f c', Attention(c, heads=8, dim_head=32, rotary_emb=rot)))).to(DEV)
+    with torch.no_grad():
+        res.fn.norm.gamma.copy_(1 + 0.2 * torch.randn_like(res.fn.norm.gamma))
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, c, f, h, w, generator=g).to(DEV)
+    dout = torch.randn(2, c, f, h, w, generator=g).to(DEV)
+    bias0 = (0.3 * torch.randn(8, f, f, generator=g)).to(DEV)
+
+    def run(hip):
+        xr = x.clone().requires_grad_(True)
+        br = bias0.clone().requires_grad_(True)
+        for p in res.parameters():
+            p.grad = None
+        out = T.temporal_attention(res, xr, br, A._rot_tables(rot, f, DEV)) if hip else A._temporal(res, xr, br)
+        out.backward(dout)
+        grads = {n: p.grad.clone() for n, p in res.named_parameters() if p.grad is not None}
+        grads["x"], grads["pos_bias"] = xr.grad.clone(), br.grad.clone()
+        return out.detach(), grads
+
+    out_ref, g_ref = run(False)
+    out_hip, g_hip = run(True)
+    tag = f"tattn_layer.c{c}"
+    assert record(tag + ".out", rel_err(out_hip, out_ref), 2e-2) < 2e-2
+    assert set(g_hip) == set(g_ref)
+    for name in sorted(g_ref):
+        assert record(f"{tag}.grad.{name}", rel_err(g_hip[name], g_ref[name]), 3e-2) < 3e-2, name
+
+
+@pytest.mark.parametrize("c,f,h,w", [(64, 3, 16, 16), (128, 2, 8, 12)])
+def test_resampling_convs_forward_backward_vs_torch(c, f, h, w):
+    """Downsample / Upsample (vdp.py:374-378) through DownsampleFn / UpsampleFn against torch's Conv3d /
+    ConvTranspose3d: output, input gradient, weight and bias gradients."""
+    from video_diffusion_amd import train_hip as T
+    from video_diffusion_amd.modules import Downsample, Upsample
+    torch.manual_seed(14)
+    for kind, mod in (("down", Downsample(c).to(DEV)), ("up", Upsample(c).to(DEV))):
+        x = torch.randn(2, c, f, h, w, device=DEV)
+        ref_out = mod(x)
+        dout = torch.randn_like(ref_out)
+        xa = x.clone().requires_grad_(True)
+        mod(xa).backward(dout)
+        ref = (ref_out.detach(), xa.grad.clone(), mod.weight.grad.clone(), mod.bias.grad.clone())
+        mod.weight.grad = mod.bias.grad = None
+        xb = x.clone().requires_grad_(True)
+        out = T.resample(mod, xb)
+        out.backward(dout)
+        tag = f"resample.{kind}.c{c}"
+        assert record(tag + ".out", rel_err(out.detach(), ref[0]), 1e-2) < 1e-2
+        assert record(tag + ".dx", rel_err(xb.grad, ref[1]), 1e-2) < 1e-2
+        assert record(tag + ".dw", rel_err(mod.weight.grad, ref[2]), 1e-2) < 1e-2
+        assert record(tag + ".db", rel_err(mod.bias.grad, ref[3]), 1e-2) < 1e-2

@@ -138,7 +138,8 @@ def train_step(args, dev):
 
     out = {"workload": f"training step: Unet3D(dim=128, channels=3) p_losses forward + backward on {tuple(x.shape)}, "
                        "random-init weights, no optimizer step", "ms_per_step": {}, "loss": {}, "peak_mem_gib": {}}
-    runs = (("hip-resnet", "hip-resnet", False), ("hip-resnet + bf16 autocast of the torch layers", "hip-resnet", True),
+    runs = (("hip + bf16 autocast of the torch layers", "hip", True), ("hip", "hip", False),
+            ("hip-resnet", "hip-resnet", False), ("hip-resnet + bf16 autocast of the torch layers", "hip-resnet", True),
             ("torch-autograd bf16 autocast", "torch-autograd", True),
             ("torch-autograd fp32", "torch-autograd", False))
     if args.train_backends:
@@ -157,10 +158,10 @@ def train_step(args, dev):
         # kernel time of ONE more hip-resnet step (after warm-up), by kernel name, from the torch profiler
         from torch.profiler import ProfilerActivity, profile
         amp = args.train_profile == "amp"
-        step("hip-resnet", amp)
+        step(args.train_profile_backend, amp)
         torch.cuda.synchronize()
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            step("hip-resnet", amp)
+            step(args.train_profile_backend, amp)
             torch.cuda.synchronize()
         rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:40]
         out["hip_resnet_step_kernels_ms"] = {e.key[:90]: [round(e.device_time_total / 1e3, 3), e.count] for e in rows}
@@ -172,6 +173,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=1)
     ap.add_argument("--train-size", type=int, default=128)
     ap.add_argument("--train-steps", type=int, default=3)
+    ap.add_argument("--train-profile-backend", default="hip")
     ap.add_argument("--train-profile", default="", help="fp32 | amp: add per-kernel times of one hip-resnet step")
     ap.add_argument("--train-backends", default="", help="comma list out of hip-resnet,torch-autograd (default: all)")
     ap.add_argument("--batch", type=int, default=16)

@@ -145,6 +145,10 @@ _SIGNATURES = {
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdmi_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "vdmi_layernorm_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    "vdmi_layernorm_rows_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    "vdmi_tattn_core_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "vdmi_tattn_core_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

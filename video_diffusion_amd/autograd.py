@@ -93,8 +93,24 @@ def _attention(att, x, pos_bias=None, focus=None):
     return att.to_out(out)
 
 
+_HIP_ATTN = False       # train_backend == "hip": the temporal attention layers too
+
+
+def _rot_tables(rot, nf, device):
+    if rot is None:
+        return None
+    if getattr(rot, "convention", "half") != "half":
+        raise NotImplementedError("the HIP temporal attention backward takes the half-split rotary convention")
+    ang = torch.arange(nf, device=device, dtype=torch.float32)[:, None] * rot.inv_freq.to(device).float()[None, :]
+    return ang.cos().contiguous(), ang.sin().contiguous()
+
+
 def _temporal(res, x, pos_bias, focus=None):
     # Residual(PreNorm(EinopsToAndFrom('b c f h w', 'b (h w) f c', Attention))), vdp.py:636
+    if _HIP_ATTN and focus is None and x.is_cuda:
+        from .train_hip import temporal_attention     # forward and backward on the HIP kernels
+        att = res.fn.fn.fn
+        return temporal_attention(res, x, pos_bias, _rot_tables(getattr(att, "rotary_emb", None), x.shape[2], x.device))
     b, c, f, h, w = x.shape
     y = _chan_layernorm(x, res.fn.norm).permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
     o = _attention(res.fn.fn.fn, y, pos_bias, focus)
@@ -107,6 +123,14 @@ def _spatial(res, x):
     y = _chan_layernorm(x, res.fn.norm).permute(0, 2, 3, 4, 1).reshape(b, f, h * w, c)
     o = _attention(res.fn.fn.fn, y)
     return o.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3) + x
+
+
+def _resample(mod, x):
+    # Downsample / Upsample, vdp.py:374-378 (nn.Identity on the last level)
+    if _HIP_ATTN and x.is_cuda and not isinstance(mod, torch.nn.Identity):
+        from .train_hip import resample
+        return resample(mod, x)
+    return mod(x)
 
 
 def _linear_attention(res, x):
@@ -163,13 +187,15 @@ def unet_forward(unet, x, time, cond=None, null_cond_prob=0., frame_cond_feature
                  focus_present_mask=None, prob_focus_present=0.):
     """Unet3D.forward (vdp.py:756-831) as differentiable torch ops over `unet`'s parameters; with
     `unet.train_backend == "hip-resnet"` the ResnetBlocks run forward and backward on the HIP kernels (train_hip.py)."""
-    global _HIP_RESNET
-    prev, _HIP_RESNET = _HIP_RESNET, getattr(unet, "train_backend", None) == "hip-resnet"
+    global _HIP_RESNET, _HIP_ATTN
+    backend = getattr(unet, "train_backend", None)
+    prev = (_HIP_RESNET, _HIP_ATTN)
+    _HIP_RESNET, _HIP_ATTN = backend in ("hip-resnet", "hip"), backend == "hip"
     try:
         return _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null_frame_cond_prob,
                              focus_present_mask, prob_focus_present)
     finally:
-        _HIP_RESNET = prev
+        _HIP_RESNET, _HIP_ATTN = prev
 
 
 def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null_frame_cond_prob, focus_present_mask,
@@ -211,7 +237,7 @@ def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null
         if ctx is not None:
             x = _cross_attention(unet.frame_cross_attns_down[i], x, ctx)
         skips.append(x)
-        x = down(x)
+        x = _resample(down, x)
     x = _resnet(unet.mid_block1, x, t)
     x = _spatial(unet.mid_spatial_attn, x)
     x = _temporal(unet.mid_temporal_attn, x, bias, focus)
@@ -224,7 +250,7 @@ def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null
         x = _temporal(tattn, x, bias, focus)
         if ctx is not None:
             x = _cross_attention(unet.frame_cross_attns_up[i], x, ctx)
-        x = up(x)
+        x = _resample(up, x)
     x = torch.cat((x, r), dim=1)
     x = _resnet(unet.final_conv[0], x, None)
     if _HIP_RESNET and x.is_cuda:

@@ -1,0 +1,394 @@
+// Training kernels of the temporal attention layer (Residual(PreNorm(Attention over frames)), reference
+// video_diffusion_pytorch/video_diffusion_pytorch.py:380-389, 531-612, 636; the gradients are those torch autograd
+// derives when the Trainer calls loss.backward(), :1451).
+//
+//   vdmi_layernorm_rows / _bwd      channel LayerNorm without gamma (gamma is folded into the projection that follows)
+//   vdmi_tattn_core_fwd / _bwd      softmax attention over the f frames of a site, heads of 32 features, on the raw q, k, v
+//                                   rows of the to_qkv projection: q scale, half-split rotary, relative-position bias,
+//                                   softmax, .v - and the backward down to the gradient of those raw rows and of the bias
+//
+// The projections themselves (to_qkv, to_out) and their gradients are row GEMMs: vdmi_tapgemm, vdmi_pack_taps_device,
+// vdmi_conv_wgrad.  The cores are vector kernels: a site's score matrix is f x f (f <= 32) per head, far below a
+// matrix-core tile, and one lane per (row, head) with the site's keys / values in LDS keeps every product in registers.
+#include "vdmi_common.h"
+
+namespace {
+
+inline bool pow2i(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// LayerNorm over channels, no affine:  xh = (x - mean) / sqrt(var + eps)   (biased variance)
+// backward:  dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh))  (+ add)
+// One row = c / 8 consecutive threads (c a power of two, 64..2048), 16-byte pieces.
+// ------------------------------------------------------------------------------------------------------------------
+struct LnArgs {
+    const __bf16* x;      // fwd: input rows; bwd: the ORIGINAL input rows (statistics are recomputed)
+    const __bf16* dxh;    // bwd only
+    const __bf16* add;    // bwd only, optional rows added to the result
+    __bf16* out;
+    long long rows;
+    int c;
+    float eps;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const LnArgs a) {
+    __shared__ float red[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LP = a.c / 8, R = 256 / LP, piece = tid % LP, rslot = tid / LP;
+    const int wpr = LP > 64 ? LP / 64 : 1;
+    auto row_sum = [&](float v, int slot) -> float {
+        const int lim = LP < 64 ? LP : 64;
+        for (int m = 1; m < lim; m <<= 1) v += __shfl_xor(v, m);
+        if (LP > 64) {
+            if (lane == 0) red[slot][wave] = v;
+            __syncthreads();
+            float s = 0.f;
+            const int w0 = (wave / wpr) * wpr;
+            for (int k = 0; k < wpr; ++k) s += red[slot][w0 + k];
+            v = s;
+        }
+        return v;
+    };
+    const long long passes = (a.rows + (long long)gridDim.x * R - 1) / ((long long)gridDim.x * R);
+    for (long long it = 0; it < passes; ++it) {
+        const long long r = (it * gridDim.x + blockIdx.x) * R + rslot;
+        const bool valid = r < a.rows;
+        const long long row = valid ? r : 0;
+        if (LP > 64) __syncthreads();
+        float xv[8];
+        {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.x + row * a.c + piece * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = (float)v[e];
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1 += xv[e]; s2 += xv[e] * xv[e]; }
+        s1 = row_sum(s1, 0);
+        s2 = row_sum(s2, 1);
+        const float mean = s1 / a.c;
+        const float rstd = rsqrtf(fmaxf(s2 / a.c - mean * mean, 0.f) + a.eps);
+        bf16x8 o;
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf((xv[e] - mean) * rstd);
+        } else {
+            float g[8], m1 = 0.f, m2 = 0.f;
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(a.dxh + row * a.c + piece * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                g[e] = (float)d[e];
+                xv[e] = (xv[e] - mean) * rstd;
+                m1 += g[e];
+                m2 += g[e] * xv[e];
+            }
+            if (LP > 64) __syncthreads();      // red[0] / red[1] are reused below
+            m1 = row_sum(m1, 2) / a.c;
+            if (LP > 64) __syncthreads();
+            m2 = row_sum(m2, 0) / a.c;
+            bf16x8 ad = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (a.add) ad = *reinterpret_cast<const bf16x8*>(a.add + row * a.c + piece * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(rstd * (g[e] - m1 - xv[e] * m2) + (float)ad[e]);
+        }
+        if (valid) *reinterpret_cast<bf16x8*>(a.out + row * a.c + piece * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Attention core over frames.  qkv rows [b*f*hw][3*heads*32] (q | k | v, column = head*32 + feature); a site's f rows
+// are hw rows apart.  A workgroup takes `spw` sites at a time; thread = (site, head, frame).
+// ------------------------------------------------------------------------------------------------------------------
+struct CoreArgs {
+    const __bf16* qkv;
+    const __bf16* o;        // bwd
+    const __bf16* dout;     // bwd: gradient of o
+    const float* lse;       // bwd: [rows][heads]
+    __bf16* out;            // fwd: o rows [rows][heads*32]; bwd: dqkv rows [rows][3*heads*32]
+    float* lse_out;         // fwd
+    float* dbias;           // bwd: [heads][f][f], accumulated
+    const float* bias;      // [heads][f][f] or null
+    const float* rot_cos;   // [f][16] or null
+    const float* rot_sin;
+    int b, f, hw, heads;
+    int spw;                // sites per workgroup pass
+    long long groups;       // ceil(b*hw / spw)
+    float scale;
+};
+
+__device__ __forceinline__ void load32(const __bf16* p, float (&v)[32]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(p + 8 * k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[8 * k + e] = (float)t[e];
+    }
+}
+__device__ __forceinline__ void store32(__bf16* p, const float (&v)[32]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = f2bf(v[8 * k + e]);
+        *reinterpret_cast<bf16x8*>(p + 8 * k) = t;
+    }
+}
+// half-split rotary of a 32-feature head (feature d pairs with d + 16); inverse = the transposed rotation
+__device__ __forceinline__ void rotate32(float (&v)[32], const float* c, const float* s, bool inverse) {
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        const float cs = c[d], sn = inverse ? -s[d] : s[d];
+        const float lo = v[d], hi = v[d + 16];
+        v[d] = lo * cs - hi * sn;
+        v[d + 16] = hi * cs + lo * sn;
+    }
+}
+__device__ __forceinline__ void lds_store32(float* p, const float (&v)[32]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x4*>(p + 4 * k) = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+}
+__device__ __forceinline__ float lds_dot32(const float* p, const float (&v)[32]) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * k), b = *reinterpret_cast<const f32x4*>(p + 4 * k + 4);
+        s0 += a[0] * v[4 * k] + a[1] * v[4 * k + 1] + a[2] * v[4 * k + 2] + a[3] * v[4 * k + 3];
+        s1 += b[0] * v[4 * k + 4] + b[1] * v[4 * k + 5] + b[2] * v[4 * k + 6] + b[3] * v[4 * k + 7];
+    }
+    return s0 + s1;
+}
+__device__ __forceinline__ void lds_axpy32(const float* p, float w, float (&acc)[32]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * k + e] += w * a[e];
+    }
+}
+
+// LDS tile of one tensor: [site][frame][head][32] floats, rows padded by 4 floats against bank conflicts between heads
+#define CORE_ROWF 36
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int F = a.f, H = a.heads, per_site = F * H, ld = 3 * H * 32, ldo = H * 32;
+    const int tile = a.spw * per_site * CORE_ROWF;                // floats per tensor
+    float* Kl = reinterpret_cast<float*>(smem);
+    float* Vl = Kl + tile;
+    float* Ql = Vl + tile;                                        // bwd only
+    float* Gl = Ql + tile;                                        // bwd only: gradient of o
+    float* Sl = Gl + tile;                                        // bwd only: [slot][2] = (lse, D)
+    float* Bl = Sl + 2 * a.spw * per_site;                        // bwd only: dbias [heads][f][f]
+    const bool active = tid < a.spw * per_site;
+    const int s = tid / per_site, rem = tid - s * per_site, h = rem / F, i = rem - h * F;
+    const int slot = (s * F + i) * H + h;                         // this thread's row slot in the tiles
+    if constexpr (BWD) {
+        for (int k = tid; k < H * F * F; k += 256) Bl[k] = 0.f;
+    }
+    float rc[16], rs[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        rc[d] = (a.rot_cos && active) ? a.rot_cos[i * 16 + d] : 1.f;
+        rs[d] = (a.rot_sin && active) ? a.rot_sin[i * 16 + d] : 0.f;
+    }
+    const long long nsites = (long long)a.b * a.hw;
+    for (long long grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
+        const long long site = grp * a.spw + s;
+        const bool valid = active && site < nsites;
+        const long long bb = valid ? site / a.hw : 0, sp = valid ? site - bb * a.hw : 0;
+        const long long row = (bb * F + i) * a.hw + sp;
+        float q[32], k[32], v[32];
+        __syncthreads();                                          // the previous pass is done with the tiles
+        if (valid) {
+            load32(a.qkv + row * ld + h * 32, q);
+            load32(a.qkv + row * ld + (H + h) * 32, k);
+            load32(a.qkv + row * ld + (2 * H + h) * 32, v);
+            rotate32(q, rc, rs, false);
+            rotate32(k, rc, rs, false);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) q[d] *= a.scale;
+            lds_store32(Kl + slot * CORE_ROWF, k);
+            lds_store32(Vl + slot * CORE_ROWF, v);
+        }
+        const float* bias_i = a.bias ? a.bias + ((long long)h * F + i) * F : nullptr;
+        if constexpr (!BWD) {
+            __syncthreads();
+            if (valid) {
+                float m = -1e30f, l = 0.f, o[32];
+#pragma unroll
+                for (int d = 0; d < 32; ++d) o[d] = 0.f;
+                for (int j = 0; j < F; ++j) {
+                    const int sj = ((s * F + j) * H + h) * CORE_ROWF;
+                    const float sc = lds_dot32(Kl + sj, q) + (bias_i ? bias_i[j] : 0.f);
+                    const float mn = fmaxf(m, sc);
+                    const float corr = __expf(m - mn), p = __expf(sc - mn);
+                    l = l * corr + p;
+#pragma unroll
+                    for (int d = 0; d < 32; ++d) o[d] *= corr;
+                    lds_axpy32(Vl + sj, p, o);
+                    m = mn;
+                }
+                const float inv = 1.0f / l;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) o[d] *= inv;
+                store32(a.out + row * ldo + h * 32, o);
+                a.lse_out[row * H + h] = m + __logf(l);
+            }
+        } else {
+            float g[32], lse = 0.f, D = 0.f;
+            if (valid) {
+                float o[32];
+                load32(a.dout + row * ldo + h * 32, g);
+                load32(a.o + row * ldo + h * 32, o);
+#pragma unroll
+                for (int d = 0; d < 32; ++d) D += g[d] * o[d];
+                lse = a.lse[row * H + h];
+                lds_store32(Ql + slot * CORE_ROWF, q);
+                lds_store32(Gl + slot * CORE_ROWF, g);
+                Sl[2 * slot] = lse;
+                Sl[2 * slot + 1] = D;
+            }
+            __syncthreads();
+            if (valid) {
+                // this row as a query: dq = sum_j dS_ij k_j,  dS_ij = p_ij (dO_i . v_j - D_i);  the bias gradient is dS
+                float dq[32];
+#pragma unroll
+                for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+                for (int j = 0; j < F; ++j) {
+                    const int sj = ((s * F + j) * H + h) * CORE_ROWF;
+                    const float sc = lds_dot32(Kl + sj, q) + (bias_i ? bias_i[j] : 0.f);
+                    const float p = __expf(sc - lse);
+                    const float ds = p * (lds_dot32(Vl + sj, g) - D);
+                    lds_axpy32(Kl + sj, ds, dq);
+                    if (a.dbias) atomicAdd(&Bl[(h * F + i) * F + j], ds);
+                }
+#pragma unroll
+                for (int d = 0; d < 32; ++d) dq[d] *= a.scale;
+                rotate32(dq, rc, rs, true);
+                store32(a.out + row * ld + h * 32, dq);
+                // this row as a key / value: dk = sum_i dS_ij q_i,  dv = sum_i p_ij dO_i   (q_i already scaled)
+                float dk[32], dv[32];
+#pragma unroll
+                for (int d = 0; d < 32; ++d) dk[d] = dv[d] = 0.f;
+                for (int qi = 0; qi < F; ++qi) {
+                    const int slq = (s * F + qi) * H + h, sq = slq * CORE_ROWF;
+                    const float bq = a.bias ? a.bias[((long long)h * F + qi) * F + i] : 0.f;
+                    const float sc = lds_dot32(Ql + sq, k) + bq;
+                    const float p = __expf(sc - Sl[2 * slq]);
+                    const float ds = p * (lds_dot32(Gl + sq, v) - Sl[2 * slq + 1]);
+                    lds_axpy32(Ql + sq, ds, dk);
+                    lds_axpy32(Gl + sq, p, dv);
+                }
+                rotate32(dk, rc, rs, true);
+                store32(a.out + row * ld + (H + h) * 32, dk);
+                store32(a.out + row * ld + (2 * H + h) * 32, dv);
+            }
+        }
+    }
+    if constexpr (BWD) {
+        __syncthreads();
+        if (a.dbias)
+            for (int k = tid; k < H * F * F; k += 256) unsafeAtomicAdd(a.dbias + k, Bl[k]);
+    }
+}
+
+size_t core_lds_bytes(bool bwd, int f, int heads, int spw) {
+    const size_t tile = (size_t)spw * f * heads * CORE_ROWF * 4;
+    return bwd ? 4 * tile + (size_t)2 * spw * f * heads * 4 + (size_t)heads * f * f * 4 : 2 * tile;
+}
+
+int core_launch(bool bwd, CoreArgs& a, hipStream_t stream) {
+    if (a.b <= 0 || a.f <= 0 || a.f > 32 || a.hw <= 0 || a.heads <= 0 || a.f * a.heads > 256) return VDMI_E_SHAPE;
+    if ((a.rot_cos == nullptr) != (a.rot_sin == nullptr)) return VDMI_E_ARG;
+    int spw = 256 / (a.f * a.heads);
+    while (spw > 1 && core_lds_bytes(bwd, a.f, a.heads, spw) > 160 * 1024) --spw;
+    const size_t lds = core_lds_bytes(bwd, a.f, a.heads, spw);
+    if (lds > 160 * 1024) return VDMI_E_LDS;
+    a.spw = spw;
+    const long long nsites = (long long)a.b * a.hw;
+    a.groups = (nsites + spw - 1) / spw;
+    if ((long long)a.b * a.f * a.hw > 0x7fffffffLL) return VDMI_E_SHAPE;
+    // persistent workgroups (the backward flushes its bias-gradient table once per workgroup)
+    const long long grid = a.groups < 1024 ? a.groups : 1024;
+    static std::atomic<uint64_t> mask_f{0}, mask_b{0};
+    if (bwd) {
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(tattn_core_kernel<true>), mask_b, 160 * 1024)) return VDMI_E_LAUNCH;
+        hipLaunchKernelGGL(tattn_core_kernel<true>, dim3((unsigned)grid), dim3(256), lds, stream, a);
+    } else {
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(tattn_core_kernel<false>), mask_f, 160 * 1024)) return VDMI_E_LAUNCH;
+        hipLaunchKernelGGL(tattn_core_kernel<false>, dim3((unsigned)grid), dim3(256), lds, stream, a);
+    }
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+int ln_check(const void* x, const void* out, int64_t rows, int c) {
+    if (!x || !out) return VDMI_E_ARG;
+    if (rows <= 0 || c < 64 || c > 2048 || !pow2i(c)) return VDMI_E_SHAPE;
+    if (!aligned16(x) || !aligned16(out)) return VDMI_E_ALIGN;
+    return VDMI_OK;
+}
+
+}   // namespace
+
+extern "C" int vdmi_layernorm_rows(const void* x, void* xh, int64_t rows, int c, float eps, vdmi_stream stream) {
+    const int st = ln_check(x, xh, rows, c);
+    if (st != VDMI_OK) return st;
+    LnArgs a{static_cast<const __bf16*>(x), nullptr, nullptr, static_cast<__bf16*>(xh), (long long)rows, c, eps};
+    const int R = 256 / (c / 8);
+    long long blocks = (rows + R - 1) / R;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(layernorm_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_layernorm_rows_bwd(const void* x, const void* dxh, const void* add, void* dx, int64_t rows, int c,
+                                       float eps, vdmi_stream stream) {
+    const int st = ln_check(x, dx, rows, c);
+    if (st != VDMI_OK) return st;
+    if (!dxh) return VDMI_E_ARG;
+    if (!aligned16(dxh) || (add && !aligned16(add))) return VDMI_E_ALIGN;
+    LnArgs a{static_cast<const __bf16*>(x), static_cast<const __bf16*>(dxh), static_cast<const __bf16*>(add),
+             static_cast<__bf16*>(dx), (long long)rows, c, eps};
+    const int R = 256 / (c / 8);
+    long long blocks = (rows + R - 1) / R;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(layernorm_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_tattn_core_fwd(const void* qkv, void* o, float* lse, const float* bias, const float* rot_cos,
+                                   const float* rot_sin, int b, int f, int hw, int heads, float scale, vdmi_stream stream) {
+    if (!qkv || !o || !lse) return VDMI_E_ARG;
+    if (!aligned16(qkv) || !aligned16(o)) return VDMI_E_ALIGN;
+    CoreArgs a{};
+    a.qkv = static_cast<const __bf16*>(qkv);
+    a.out = static_cast<__bf16*>(o);
+    a.lse_out = lse;
+    a.bias = bias; a.rot_cos = rot_cos; a.rot_sin = rot_sin;
+    a.b = b; a.f = f; a.hw = hw; a.heads = heads; a.scale = scale;
+    return core_launch(false, a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
+                                   float* dbias, const float* bias, const float* rot_cos, const float* rot_sin, int b, int f,
+                                   int hw, int heads, float scale, vdmi_stream stream) {
+    if (!qkv || !o || !dout || !lse || !dqkv) return VDMI_E_ARG;
+    if (dbias && !bias) return VDMI_E_ARG;
+    if (!aligned16(qkv) || !aligned16(o) || !aligned16(dout) || !aligned16(dqkv)) return VDMI_E_ALIGN;
+    CoreArgs a{};
+    a.qkv = static_cast<const __bf16*>(qkv);
+    a.o = static_cast<const __bf16*>(o);
+    a.dout = static_cast<const __bf16*>(dout);
+    a.lse = lse;
+    a.out = static_cast<__bf16*>(dqkv);
+    a.dbias = dbias;
+    a.bias = bias; a.rot_cos = rot_cos; a.rot_sin = rot_sin;
+    a.b = b; a.f = f; a.hw = hw; a.heads = heads; a.scale = scale;
+    return core_launch(true, a, static_cast<hipStream_t>(stream));
+}

@@ -387,7 +387,7 @@ class Unet3D(nn.Module):
         # reference: vdp.py:756-831
         assert not (self.has_cond and not exists(cond)), 'cond must be passed in if cond_dim specified'
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            if self.train_backend in ("torch-autograd", "hip-resnet"):
+            if self.train_backend in ("torch-autograd", "hip-resnet", "hip"):
                 # training: the same arithmetic as differentiable torch ops (autograd.py), as the reference trains
                 from . import autograd
                 return autograd.unet_forward(self, x, time, cond=cond, null_cond_prob=null_cond_prob,

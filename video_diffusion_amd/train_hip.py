@@ -43,14 +43,15 @@ def from_rows(r: torch.Tensor, b: int, f: int, h: int, w: int) -> torch.Tensor:
 class DevPack:
     """A weight set in the tap-GEMM's fragment order, packed on the device (weights change every optimizer step)."""
 
-    def __init__(self, weight: torch.Tensor, transposed: bool):
-        # weight: a Conv3d weight (cout, cin, 1, kh, kw).  transposed: the set of the input-gradient pass
+    def __init__(self, weight: torch.Tensor, transposed: bool, tile_bn=None):
+        # weight: a Conv3d weight (cout, cin, 1, kh, kw), or the same as [cout][cin][taps].  transposed: the set of the
+        # input-gradient pass.  tile_bn: 64 forces 64-channel output tiles, 0 the automatic tile, None picks by width
         cout, cin = weight.shape[0], weight.shape[1]
-        ntaps = weight.shape[2] * weight.shape[3] * weight.shape[4]
+        ntaps = weight[0, 0].numel()
         w3 = weight.detach().reshape(cout, cin, ntaps).to(torch.float32).contiguous()
         self.n, self.k = (cin, cout) if transposed else (cout, cin)
         self.ntaps = ntaps
-        self.tile_bn = 64 if (self.n >= 256 and self.n % 64 == 0) else 0
+        self.tile_bn = (64 if (self.n >= 256 and self.n % 64 == 0) else 0) if tile_bn is None else tile_bn
         if self.tile_bn == 64:
             self.bn, self.bkc = 64, 64
         else:
@@ -109,11 +110,13 @@ def rows_transposed(rows: torch.Tensor, nf: int, hw: int) -> torch.Tensor:
     return out
 
 
-def conv_wgrad(x_t: torch.Tensor, dy_t: torch.Tensor, cin: int, cout: int, nf: int, h: int, w: int, ntaps: int) -> torch.Tensor:
-    """float32 (cout, cin, 1, k, k) weight gradient from the transposed operands."""
+def conv_wgrad(x_t: torch.Tensor, dy_t: torch.Tensor, cin: int, cout: int, nf: int, h: int, w: int, ntaps: int,
+               tap=(0, 0)) -> torch.Tensor:
+    """float32 (cout, cin, 1, k, k) weight gradient from the transposed operands; `tap`: the pixel offset of the
+    one-tap form (dw[co][ci] = sum_p dy[p][co] x[p + tap][ci])."""
     k = 3 if ntaps == 9 else 1
     dw = torch.zeros(cout, cin, 1, k, k, device=x_t.device, dtype=torch.float32)
-    taps = _TAPS_3x3 if ntaps == 9 else _TAPS_1x1
+    taps = _TAPS_3x3 if ntaps == 9 else [tuple(tap)]
     dy = (C.c_int8 * ntaps)(*[t[0] for t in taps])
     dx = (C.c_int8 * ntaps)(*[t[1] for t in taps])
     lib = _lib.lib()
@@ -295,3 +298,229 @@ def resnet_block(rb, x: torch.Tensor, temb) -> torch.Tensor:
     wres, bres = (rc.weight, rc.bias) if isinstance(rc, torch.nn.Conv3d) else (None, None)
     return ResnetBlockFn.apply(x, scale, shift, rb.block1.proj.weight, rb.block1.proj.bias, rb.block1.norm.gamma,
                                rb.block2.proj.weight, rb.block2.proj.bias, rb.block2.norm.gamma, wres, bres)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# temporal attention layer: Residual(PreNorm(EinopsToAndFrom('b c f h w', 'b (h w) f c', Attention)))
+# ---------------------------------------------------------------------------------------------------------------------
+def _linear_pack(w2: torch.Tensor, transposed: bool) -> DevPack:
+    """A Linear weight [n][k] as a one-tap weight set."""
+    return DevPack(w2.reshape(w2.shape[0], w2.shape[1], 1, 1, 1), transposed)
+
+
+class TemporalAttnFn(torch.autograd.Function):
+    """vdp.py:380-389 (LayerNorm), 531-612 (Attention with rotary and relative-position bias), 331-337 (Residual) over
+    x float (B, C, F, H, W): forward and backward on the HIP kernels.  gamma (1, C, 1, 1, 1); wqkv (3*heads*32, C);
+    wout (C, heads*32); bias float [heads][F][F] (may require grad); cos / sin float [F][16] or None."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, gamma, wqkv, wout, bias, cos, sin, heads, scale, eps):
+        if not x.is_cuda:
+            raise _lib.VdmiError("the HIP training backend needs CUDA (HIP) tensors; there is no CPU path")
+        lib = _lib.lib()
+        b, c, f, h, w = x.shape
+        hw, rows, hid = h * w, b * f * h * w, heads * 32
+        assert wqkv.shape == (3 * hid, c) and wout.shape == (c, hid)
+        xr = to_rows(x)
+        xh = torch.empty_like(xr)
+        check(lib.vdmi_layernorm_rows(xr.data_ptr(), xh.data_ptr(), rows, c, eps, _stream()), "vdmi_layernorm_rows")
+        wp = (wqkv.detach() * gamma.detach().reshape(1, c)).contiguous()            # LayerNorm gamma folded into to_qkv
+        qkv = conv_rows(xh, _linear_pack(wp, False), None, b * f, f, h, w)
+        o = torch.empty(rows, hid, device=x.device, dtype=torch.bfloat16)
+        lse = torch.empty(rows, heads, device=x.device, dtype=torch.float32)
+        bias_c = None if bias is None else bias.detach().float().contiguous()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        check(lib.vdmi_tattn_core_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ptr(bias_c), ptr(cos), ptr(sin), b, f, hw,
+                                      heads, scale, _stream()), "vdmi_tattn_core_fwd")
+        y = conv_rows(o, _linear_pack(wout.detach().contiguous(), False), None, b * f, f, h, w, residual=xr)
+        ctx.save_for_backward(xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin)
+        ctx.meta = (b, c, f, h, w, heads, scale, eps)
+        return from_rows(y, b, f, h, w)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin = ctx.saved_tensors
+        b, c, f, h, w, heads, scale, eps = ctx.meta
+        lib = _lib.lib()
+        hw, rows, hid, frames = h * w, b * f * h * w, heads * 32, b * f
+        ptr = lambda t: None if t is None else t.data_ptr()
+        dyr = to_rows(dy)
+        # to_out: gradient of its input and of its weight
+        do = conv_rows(dyr, _linear_pack(wout.detach().contiguous(), True), None, frames, f, h, w)
+        dyr_t = rows_transposed(dyr, frames, hw)
+        dwout = conv_wgrad(rows_transposed(o, frames, hw), dyr_t, hid, c, frames, h, w, 1).reshape(c, hid)
+        # attention core
+        dqkv = torch.empty_like(qkv)
+        dbias = torch.zeros_like(bias_c) if bias_c is not None else None
+        check(lib.vdmi_tattn_core_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                      ptr(dbias), ptr(bias_c), ptr(cos), ptr(sin), b, f, hw, heads, scale, _stream()),
+              "vdmi_tattn_core_bwd")
+        # to_qkv (with the folded gamma), LayerNorm, residual
+        dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
+        dwp = conv_wgrad(rows_transposed(xh, frames, hw), rows_transposed(dqkv, frames, hw), c, 3 * hid, frames, h, w,
+                         1).reshape(3 * hid, c)
+        dwqkv = dwp * gamma.detach().reshape(1, c)
+        dgamma = (dwp * wqkv.detach()).sum(0).reshape(gamma.shape)
+        dx = torch.empty_like(xr)
+        check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
+                                          _stream()), "vdmi_layernorm_rows_bwd")
+        return from_rows(dx, b, f, h, w), dgamma, dwqkv, dwout, dbias, None, None, None, None, None
+
+
+def temporal_attention(res, x: torch.Tensor, pos_bias, rot_tables) -> torch.Tensor:
+    """autograd.py's `_temporal` (no focus mask) on the HIP kernels.  rot_tables: (cos, sin) float [F][16] or None."""
+    att = res.fn.fn.fn
+    if att.dim_head != 32:
+        raise _lib.VdmiError("the HIP temporal attention takes heads of 32 features")
+    cos, sin = rot_tables if rot_tables is not None else (None, None)
+    return TemporalAttnFn.apply(x, res.fn.norm.gamma, att.to_qkv.weight, att.to_out.weight, pos_bias, cos, sin, att.heads,
+                                float(att.scale), float(res.fn.norm.eps))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Downsample / Upsample (vdp.py:374-378): Conv3d (1,4,4) / stride 2 / pad 1 and its transposed twin
+# ---------------------------------------------------------------------------------------------------------------------
+_UP_PAIRS = {0: [(1, 0), (3, -1)], 1: [(0, 1), (2, 0)]}     # output parity -> (kernel index, input offset) pairs
+
+
+def down_conv_rows(x: torch.Tensor, weight: torch.Tensor, bias, frames: int, fpb: int, h: int, w: int) -> torch.Tensor:
+    """Conv3d(cin, n, (1,4,4), stride 2, pad 1) over rows of an h x w image -> rows of the (h/2) x (w/2) image, as a
+    2x2 / stride-1 tap-GEMM over the space-to-depth view of x.  weight (n, cin, 1, 4, 4)."""
+    n, cin = weight.shape[0], weight.shape[1]
+    if h % 2 or w % 2 or cin % 64:
+        raise _lib.VdmiError("the HIP resampling convolutions take even images and channel widths that are multiples of 64")
+    w4 = weight.detach()[:, :, 0].float()
+    # channel (2a+b)*cin + ci, tap (dY, dX)  <-  kernel element (2dY+a, 2dX+b)
+    w2 = torch.cat([torch.stack([w4[:, :, 2 * dy + a, 2 * dx + b] for dy in (0, 1) for dx in (0, 1)], dim=-1)
+                    for a in (0, 1) for b in (0, 1)], dim=1)
+    pack = DevPack(w2, False, tile_bn=64)
+    oh, ow = h // 2, w // 2
+    out = torch.empty(frames * oh * ow, n, device=x.device, dtype=torch.bfloat16)
+    a = TapGemmArgs()
+    a.frames, a.frames_per_batch = frames, fpb
+    a.grid_h, a.grid_w, a.out_h, a.out_w = oh, ow, oh, ow
+    a.out_mul = 1
+    a.out, a.ldo, a.n, a.epilogue = out.data_ptr(), n, n, EPI_PLAIN
+    p = a.main
+    p.src0, p.c0, p.c1 = x.data_ptr(), 4 * cin, 0
+    p.in_h, p.in_w, p.stride, p.ntaps = h, w, 1, 4
+    for i, (dy, dx) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        p.dy[i], p.dx[i] = dy, dx
+    p.w = pack.data.data_ptr()
+    p.space_to_depth = 1
+    a.bias = None if bias is None else bias.data_ptr()
+    a.tile_bn = 64
+    check(_lib.lib().vdmi_tapgemm(C.byref(a), _stream()), "vdmi_tapgemm")
+    return out
+
+
+def up_conv_rows(x: torch.Tensor, weight: torch.Tensor, bias, frames: int, fpb: int, h: int, w: int) -> torch.Tensor:
+    """ConvTranspose3d(cin, n, (1,4,4), stride 2, pad 1) over rows of an h x w image -> rows of the 2h x 2w image: the four
+    output parities as four 4-tap phases of one launch.  weight (cin, n, 1, 4, 4)."""
+    cin, n = weight.shape[0], weight.shape[1]
+    w4 = weight.detach()[:, :, 0].float()
+    packs = []
+    for pp in (0, 1):
+        for q in (0, 1):
+            taps = torch.stack([w4[:, :, ky, kx].t() for (ky, _) in _UP_PAIRS[pp] for (kx, _) in _UP_PAIRS[q]], dim=-1)
+            packs.append(DevPack(taps, False, tile_bn=0).data)
+    wall = torch.cat(packs).contiguous()
+    oh, ow = 2 * h, 2 * w
+    out = torch.empty(frames * oh * ow, n, device=x.device, dtype=torch.bfloat16)
+    taps = [(dy, dx) for pp in (0, 1) for q in (0, 1) for (_, dy) in _UP_PAIRS[pp] for (_, dx) in _UP_PAIRS[q]]
+    a = TapGemmArgs()
+    a.frames, a.frames_per_batch = frames, fpb
+    a.grid_h, a.grid_w, a.out_h, a.out_w = h, w, oh, ow
+    a.out_mul, a.out_off_y, a.out_off_x = 2, 0, 0
+    a.out, a.ldo, a.n, a.epilogue = out.data_ptr(), n, n, EPI_PLAIN
+    p = a.main
+    p.src0, p.c0, p.c1 = x.data_ptr(), cin, 0
+    p.in_h, p.in_w, p.stride, p.ntaps = h, w, 1, len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        p.dy[i], p.dx[i] = dy, dx
+    p.w = wall.data_ptr()
+    p.phases, p.w_phase_stride = 4, packs[0].numel()
+    a.bias = None if bias is None else bias.data_ptr()
+    check(_lib.lib().vdmi_tapgemm(C.byref(a), _stream()), "vdmi_tapgemm")
+    return out
+
+
+def strided_wgrad(big: torch.Tensor, small: torch.Tensor, frames: int, h: int, w: int) -> torch.Tensor:
+    """dW[cs][cb][ky][kx] = sum over frames and small-image pixels q of small[q][cs] * big[2q + (ky-1, kx-1)][cb]: the
+    weight gradient of the (1,4,4) / stride 2 / pad 1 convolution from big (h x w) to small (h/2 x w/2), and - with the
+    roles of input and output gradient swapped - of its transposed twin.  Four one-tap gradients over the
+    space-to-depth view of `big`."""
+    cb, cs = big.shape[1], small.shape[1]
+    oh, ow = h // 2, w // 2
+    bp = F.pad(big.view(frames, h, w, cb), (0, 0, 1, 1, 1, 1))                      # zero border of one pixel
+    s2d = bp.view(frames, oh + 1, 2, ow + 1, 2, cb).permute(0, 1, 3, 2, 4, 5).reshape(frames * (oh + 1) * (ow + 1), 4 * cb)
+    sp = F.pad(small.view(frames, oh, ow, cs), (0, 0, 0, 1, 0, 1)).reshape(frames * (oh + 1) * (ow + 1), cs)
+    hw2 = (oh + 1) * (ow + 1)
+    big_t = rows_transposed(s2d.contiguous(), frames, hw2)
+    small_t = rows_transposed(sp.contiguous(), frames, hw2)
+    dw = torch.empty(cs, cb, 4, 4, device=big.device, dtype=torch.float32)
+    for ty in (0, 1):
+        for tx in (0, 1):
+            d2 = conv_wgrad(big_t, small_t, 4 * cb, cs, frames, oh + 1, ow + 1, 1, tap=(ty, tx)).view(cs, 2, 2, cb)
+            for a in (0, 1):
+                for b in (0, 1):
+                    dw[:, :, 2 * ty + a, 2 * tx + b] = d2[:, a, b]
+    return dw.view(cs, cb, 1, 4, 4)
+
+
+class DownsampleFn(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias):
+        b, c, f, h, w = x.shape
+        xr = to_rows(x)
+        y = down_conv_rows(xr, weight, bias.detach().float().contiguous(), b * f, f, h, w)
+        ctx.save_for_backward(xr, weight)
+        ctx.dims = (b, f, h, w)
+        return from_rows(y, b, f, h // 2, w // 2)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        xr, weight = ctx.saved_tensors
+        b, f, h, w = ctx.dims
+        dyr = to_rows(dy)
+        # the input gradient of a strided convolution is the transposed convolution with the same weight tensor
+        dx = up_conv_rows(dyr, weight, None, b * f, f, h // 2, w // 2)
+        dw = strided_wgrad(xr, dyr, b * f, h, w)
+        return from_rows(dx, b, f, h, w), dw, colsum_rows(dyr)
+
+
+class UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias):
+        b, c, f, h, w = x.shape
+        xr = to_rows(x)
+        y = up_conv_rows(xr, weight, bias.detach().float().contiguous(), b * f, f, h, w)
+        ctx.save_for_backward(xr, weight)
+        ctx.dims = (b, f, h, w)
+        return from_rows(y, b, f, 2 * h, 2 * w)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        xr, weight = ctx.saved_tensors
+        b, f, h, w = ctx.dims
+        dyr = to_rows(dy)
+        # ... and the input gradient of the transposed convolution is the strided convolution with the same weight tensor
+        dx = down_conv_rows(dyr, weight, None, b * f, f, 2 * h, 2 * w)
+        dw = strided_wgrad(dyr, xr, b * f, 2 * h, 2 * w)
+        return from_rows(dx, b, f, h, w), dw, colsum_rows(dyr)
+
+
+def resample(mod, x: torch.Tensor) -> torch.Tensor:
+    """Downsample / Upsample modules of the reference (vdp.py:374-378) on the HIP kernels; anything else runs as it is."""
+    k, st, pd = (1, 4, 4), (1, 2, 2), (0, 1, 1)
+    if isinstance(mod, torch.nn.ConvTranspose3d) and (mod.kernel_size, mod.stride, mod.padding) == (k, st, pd):
+        return UpsampleFn.apply(x, mod.weight, mod.bias)
+    if isinstance(mod, torch.nn.Conv3d) and (mod.kernel_size, mod.stride, mod.padding) == (k, st, pd):
+        return DownsampleFn.apply(x, mod.weight, mod.bias)
+    return mod(x)
