@@ -230,8 +230,9 @@ def test_trainer_hip_resnet_backend_follows_torch_backend(tmp_path):
         return [l["loss"] for l in logs], tr
 
     ref, _ = run("torch-autograd", str(tmp_path / "r0"))
-    hip, tr = run("hip-resnet", str(tmp_path / "r1"))
-    assert len(ref) == len(hip) == 3
-    for i, (a, b) in enumerate(zip(hip, ref)):
-        assert record(f"trainer_hip_resnet.loss_step{i}", abs(a - b) / abs(b), 3e-2) < 3e-2
-    assert tr.model.denoise_fn.train_backend == "hip-resnet"
+    for k, backend in enumerate(("hip-resnet", "hip")):      # "hip": temporal attention and resampling convs too
+        hip, tr = run(backend, str(tmp_path / f"r{k + 1}"))
+        assert len(ref) == len(hip) == 3
+        for i, (a, b) in enumerate(zip(hip, ref)):
+            assert record(f"trainer_{backend}.loss_step{i}", abs(a - b) / abs(b), 3e-2) < 3e-2
+        assert tr.model.denoise_fn.train_backend == backend

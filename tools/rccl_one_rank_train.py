@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Data-parallel training over RCCL with a world of ONE rank (all a one-GPU box offers): the Trainer wraps its loss
 module in DistributedDataParallel on the "nccl" backend, so the bucketed gradient all-reduce runs over RCCL on device
-tensors - with the ResnetBlocks' forward and backward on the HIP kernels (train_backend "hip-resnet")."""
+tensors - with the ResnetBlocks, temporal attention layers and resampling convolutions forward and backward on the HIP
+kernels (train_backend "hip")."""
 import os
 import sys
 import tempfile
@@ -33,7 +34,7 @@ with tempfile.TemporaryDirectory() as tmp:
     tr = Trainer(gd, folder, num_prev_frames=2, train_batch_size=2, train_num_steps=2, gradient_accumulate_every=2,
                  step_start_ema=0, update_ema_every=1, save_and_sample_every=10 ** 6, results_folder=os.path.join(tmp, "r"))
     assert tr.distributed
-    tr.train_backend = "hip-resnet"
+    tr.train_backend = "hip"
     before = gd.denoise_fn.downs[0][0].block1.proj.weight.detach().clone()
     logs = []
     tr.train(log_fn=logs.append)
