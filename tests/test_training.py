@@ -216,13 +216,13 @@ def test_trainer_hip_resnet_backend_follows_torch_backend(tmp_path):
     _write_gifs(folder, n=4, frames=6, size=36)
     dev = torch.device("cuda:0")
 
-    def run(backend, results):
+    def run(backend, results, amp=False):
         torch.manual_seed(0)
         unet = Unet3D(dim=64, dim_mults=(1, 2), channels=4)
         vae = VAE(channels=3, latent_dim=4, base_dim=64)
         gd = GaussianDiffusion(unet, vae, image_size=32, num_frames=4, channels=3, timesteps=50).to(dev)
         tr = Trainer(gd, folder, num_prev_frames=2, train_batch_size=2, train_num_steps=3, gradient_accumulate_every=1,
-                     step_start_ema=0, update_ema_every=1, save_and_sample_every=10 ** 6, results_folder=results)
+                     step_start_ema=0, update_ema_every=1, save_and_sample_every=10 ** 6, results_folder=results, amp=amp)
         tr.train_backend = backend
         torch.manual_seed(1)                      # the data order and the (t, noise) draws of the loss
         logs = []
@@ -236,3 +236,8 @@ def test_trainer_hip_resnet_backend_follows_torch_backend(tmp_path):
         for i, (a, b) in enumerate(zip(hip, ref)):
             assert record(f"trainer_{backend}.loss_step{i}", abs(a - b) / abs(b), 3e-2) < 3e-2
         assert tr.model.denoise_fn.train_backend == backend
+    # Trainer(amp=True): the torch layers run under autocast with a gradient scaler, the HIP layers take the scaled
+    # gradients in bf16 (fp32's exponent range); the loss follows the full-precision run
+    amp_losses, _ = run("hip", str(tmp_path / "r_amp"), amp=True)
+    for i, (a, b) in enumerate(zip(amp_losses, ref)):
+        assert record(f"trainer_hip_amp.loss_step{i}", abs(a - b) / abs(b), 5e-2) < 5e-2
