@@ -374,3 +374,66 @@ def test_resampling_convs_forward_backward_vs_torch(c, f, h, w):
         assert record(tag + ".dx", rel_err(xb.grad, ref[1]), 1e-2) < 1e-2
         assert record(tag + ".dw", rel_err(mod.weight.grad, ref[2]), 1e-2) < 1e-2
         assert record(tag + ".db", rel_err(mod.bias.grad, ref[3]), 1e-2) < 1e-2
+
+
+@pytest.mark.parametrize("frames,n,heads", [(3, 100, 4), (2, 2500, 4), (5, 64, 8)])
+def test_sla_core_forward_backward_vs_torch(frames, n, heads):
+    """The linear-attention core (vdp.py:467-477) on raw q, k, v rows: reduction partials + row kernels against torch."""
+    from video_diffusion_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(15)
+    rows, hid, scale = frames * n, heads * 32, 32 ** -0.5
+    qkv = _bf(torch.randn(rows, 3 * hid, generator=g) * 1.5).to(DEV)
+    dout = _bf(torch.randn(rows, hid, generator=g)).to(DEV)
+    nbytes = lib.vdmi_sla_train_partial_bytes(frames, n, heads)
+    p_ctx = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    p_dctx = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    base = qkv.data_ptr()
+    _lib.check(lib.vdmi_sla_train_reduce(base + 2 * hid, 3 * hid, base + 4 * hid, 3 * hid, p_ctx.data_ptr(), frames, n, heads, 0, None))
+    out, qt, dqkv = (torch.empty(rows, hid, device=DEV, dtype=torch.bfloat16), torch.empty(rows, hid, device=DEV, dtype=torch.bfloat16),
+                     torch.empty_like(qkv))
+    _lib.check(lib.vdmi_sla_train_rows_fwd(qkv.data_ptr(), p_ctx.data_ptr(), out.data_ptr(), qt.data_ptr(), frames, n, heads, scale, None))
+    _lib.check(lib.vdmi_sla_train_reduce(qt.data_ptr(), hid, dout.data_ptr(), hid, p_dctx.data_ptr(), frames, n, heads, 1, None))
+    _lib.check(lib.vdmi_sla_train_rows_bwd(qkv.data_ptr(), qt.data_ptr(), dout.data_ptr(), p_ctx.data_ptr(), p_dctx.data_ptr(),
+                                           dqkv.data_ptr(), frames, n, heads, scale, None))
+    qr = qkv.double().requires_grad_(True)
+    t = qr.view(frames, n, 3, heads, 32).permute(2, 0, 3, 4, 1)            # [3][frames][heads][32][n]
+    q, k, v = t[0].softmax(dim=-2) * scale, t[1].softmax(dim=-1), t[2]
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    ref = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(rows, hid)
+    ref.backward(dout.double())
+    tag = f"sla_core.n{n}.h{heads}"
+    assert record(tag + ".out", rel_err(out.float().cpu(), ref.detach().cpu()), 5e-3) < 5e-3
+    assert record(tag + ".dqkv", rel_err(dqkv.float().cpu(), qr.grad.cpu()), 1.5e-2) < 1.5e-2
+
+
+@pytest.mark.parametrize("c,f,h,w", [(64, 3, 16, 16), (256, 2, 8, 8)])
+def test_linear_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w):
+    """Residual(PreNorm(SpatialLinearAttention)) (vdp.py:454-479) through SlaFn against the torch ops of autograd.py."""
+    from video_diffusion_amd import autograd as A, train_hip as T
+    from video_diffusion_amd.modules import PreNorm, Residual, SpatialLinearAttention
+    torch.manual_seed(16)
+    res = Residual(PreNorm(c, SpatialLinearAttention(c, heads=4))).to(DEV)
+    with torch.no_grad():
+        res.fn.norm.gamma.copy_(1 + 0.2 * torch.randn_like(res.fn.norm.gamma))
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, c, f, h, w, generator=g).to(DEV)
+    dout = torch.randn(2, c, f, h, w, generator=g).to(DEV)
+
+    def run(hip):
+        xr = x.clone().requires_grad_(True)
+        for p in res.parameters():
+            p.grad = None
+        out = T.spatial_linear_attention(res, xr) if hip else A._linear_attention(res, xr)
+        out.backward(dout)
+        grads = {n: p.grad.clone() for n, p in res.named_parameters() if p.grad is not None}
+        grads["x"] = xr.grad.clone()
+        return out.detach(), grads
+
+    out_ref, g_ref = run(False)
+    out_hip, g_hip = run(True)
+    tag = f"sla_layer.c{c}"
+    assert record(tag + ".out", rel_err(out_hip, out_ref), 2e-2) < 2e-2
+    assert set(g_hip) == set(g_ref)
+    for name in sorted(g_ref):
+        assert record(f"{tag}.grad.{name}", rel_err(g_hip[name], g_ref[name]), 3e-2) < 3e-2, name

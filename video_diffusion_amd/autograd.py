@@ -136,6 +136,9 @@ def _resample(mod, x):
 def _linear_attention(res, x):
     sl = res.fn.fn
     b, c, f, h, w = x.shape
+    if _HIP_ATTN and x.is_cuda and isinstance(sl.to_qkv, torch.nn.Conv2d):
+        from .train_hip import spatial_linear_attention     # forward and backward on the HIP kernels
+        return spatial_linear_attention(res, x)
     y = _chan_layernorm(x, res.fn.norm)
     if isinstance(sl.to_qkv, torch.nn.Linear):
         # SpatioTemporalAttention, version1diffusion.py:325-345

@@ -392,3 +392,261 @@ extern "C" int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* d
     a.b = b; a.f = f; a.hw = hw; a.heads = heads; a.scale = scale;
     return core_launch(true, a, static_cast<hipStream_t>(stream));
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// SpatialLinearAttention (vdp.py:454-479), training form.  Per (frame, head), n = h*w positions, 32 features:
+//   Kt = softmax over the positions of k,   Qt = softmax over the features of q, times scale
+//   ctx[d][e] = sum_n Kt[n][d] v[n][e],     out[n][e] = sum_d Qt[n][d] ctx[d][e]
+// Backward (with dctx[d][e] = sum_n Qt[n][d] dout[n][e] and S[d] = sum_e dctx[d][e] ctx[d][e], which equals
+// sum_n Kt[n][d] dKt[n][d]):
+//   dq = scale * sigma * (dQt - sigma . dQt),  dQt[d] = ctx[d][:] . dout      (sigma = Qt / scale)
+//   dk[n][d] = Kt[n][d] * (dctx[d][:] . v[n] - S[d]),    dv[n][e] = sum_d Kt[n][d] dctx[d][e]
+// Two kinds of kernel: a reduction over positions that leaves per-split partial 32 x 32 sums (with an online softmax
+// of the first operand for ctx), and row kernels (one lane per (row, head)) that first combine the partials of their
+// frame in LDS.  Rows: row = frame * n + position, column = head * 32 + feature.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int SLA_SPLIT = 1024;               // positions per reduction workgroup
+constexpr int SLA_PART = 32 * 32 + 64;        // floats per partial: sums [32][32], then max [32], then weight sum [32]
+
+struct SlaRedArgs {
+    const __bf16* a; int lda;                 // first operand rows (k, or the saved Qt), already offset to its columns
+    const __bf16* b; int ldb;                 // second operand rows (v, or dout)
+    float* part;                              // [frame][head][split][SLA_PART]
+    int n, heads, nsplit;
+};
+
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256) void sla_reduce_kernel(const SlaRedArgs a) {
+    __shared__ float al[64][33];
+    __shared__ __attribute__((aligned(16))) float bl[64][32];
+    const int tid = threadIdx.x, d = tid >> 3, e0 = (tid & 7) * 4;
+    const int split = blockIdx.x, head = blockIdx.y, frame = blockIdx.z;
+    const int p_begin = split * SLA_SPLIT, p_end = min(p_begin + SLA_SPLIT, a.n);
+    float m = -1e30f, z = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+        __syncthreads();
+        {   // one 16-byte piece of each operand per thread: position tid / 4, features (tid % 4) * 8 ..
+            const int pp = tid >> 2, f8 = (tid & 3) * 8, pos = p0 + pp;
+            bf16x8 va = {0, 0, 0, 0, 0, 0, 0, 0}, vb = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (pos < p_end) {
+                const long long row = (long long)frame * a.n + pos;
+                va = *reinterpret_cast<const bf16x8*>(a.a + row * a.lda + head * 32 + f8);
+                vb = *reinterpret_cast<const bf16x8*>(a.b + row * a.ldb + head * 32 + f8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { al[pp][f8 + j] = (float)va[j]; bl[pp][f8 + j] = (float)vb[j]; }
+        }
+        __syncthreads();
+        const int cnt = min(64, p_end - p0);
+        for (int pp = 0; pp < cnt; ++pp) {
+            float w = al[pp][d];
+            if constexpr (SOFTMAX) {
+                if (w > m) {
+                    const float corr = __expf(m - w);
+                    z *= corr;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] *= corr;
+                    m = w;
+                }
+                w = __expf(w - m);
+                z += w;
+            }
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&bl[pp][e0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += w * bv[j];
+        }
+    }
+    float* out = a.part + (((long long)frame * a.heads + head) * a.nsplit + split) * SLA_PART;
+    *reinterpret_cast<f32x4*>(out + d * 32 + e0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    if ((tid & 7) == 0) { out[1024 + d] = m; out[1056 + d] = z; }
+}
+
+struct SlaRowsArgs {
+    const __bf16* qkv;        // [rows][3*heads*32]
+    const __bf16* qt;         // bwd: saved Qt rows [rows][heads*32]
+    const __bf16* dout;       // bwd: gradient of out [rows][heads*32]
+    const float* part_ctx;    // partials of the softmax reduction (k, v)
+    const float* part_dctx;   // bwd: partials of the plain reduction (Qt, dout)
+    __bf16* out;              // fwd: out rows [rows][heads*32]; bwd: dqkv rows [rows][3*heads*32]
+    __bf16* qt_out;           // fwd: Qt rows
+    int n, heads, nsplit, frames;
+    float scale;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void sla_rows_kernel(const SlaRowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.heads, tid = threadIdx.x;
+    float* ctx = reinterpret_cast<float*>(smem);          // [H][32][32]
+    float* dctx = ctx + H * 1024;                         // bwd: [H][32][32]
+    float* mx = dctx + (BWD ? H * 1024 : 0);              // bwd: [H][32] max, then 1 / weight sum, then S
+    float* zinv = mx + H * 32;
+    float* sd = zinv + H * 32;
+    const int frame = blockIdx.y;
+    // ---- combine the partials of this frame ------------------------------------------------------------------------
+    for (int i = tid; i < H * 1024; i += 256) {
+        const int h = i >> 10, dd = (i >> 5) & 31, e = i & 31;
+        const float* p = a.part_ctx + ((long long)frame * H + h) * a.nsplit * SLA_PART;
+        float M = -1e30f;
+        for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, p[s * SLA_PART + 1024 + dd]);
+        float num = 0.f, den = 0.f;
+        for (int s = 0; s < a.nsplit; ++s) {
+            const float w = __expf(p[s * SLA_PART + 1024 + dd] - M);
+            num += p[s * SLA_PART + dd * 32 + e] * w;
+            den += p[s * SLA_PART + 1056 + dd] * w;
+        }
+        ctx[i] = num / den;
+        if constexpr (BWD) {
+            if (e == 0) { mx[h * 32 + dd] = M; zinv[h * 32 + dd] = 1.0f / den; }
+            const float* q = a.part_dctx + ((long long)frame * H + h) * a.nsplit * SLA_PART;
+            float sum = 0.f;
+            for (int s = 0; s < a.nsplit; ++s) sum += q[s * SLA_PART + dd * 32 + e];
+            dctx[i] = sum;
+        }
+    }
+    __syncthreads();
+    if constexpr (BWD) {
+        for (int i = tid; i < H * 32; i += 256) {
+            float s = 0.f;
+            for (int e = 0; e < 32; ++e) s += dctx[i * 32 + e] * ctx[i * 32 + e];
+            sd[i] = s;
+        }
+        __syncthreads();
+    }
+    // ---- rows: thread = (head, row of the block); a wave's lanes share the head --------------------------------------
+    const int rb = 256 / H, h = tid / rb, r = tid - h * rb;
+    const int pos = blockIdx.x * rb + r;
+    if (h >= H || pos >= a.n) return;
+    const long long row = (long long)frame * a.n + pos;
+    const int ld = 3 * H * 32, ldo = H * 32;
+    const float* cx = ctx + h * 1024;
+    if constexpr (!BWD) {
+        float q[32];
+        load32(a.qkv + row * ld + h * 32, q);
+        float m = q[0];
+#pragma unroll
+        for (int dd = 1; dd < 32; ++dd) m = fmaxf(m, q[dd]);
+        float l = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 32; ++dd) { q[dd] = __expf(q[dd] - m); l += q[dd]; }
+        const float inv = a.scale / l;
+        float o[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 32; ++dd) {
+            q[dd] *= inv;
+            lds_axpy32(cx + dd * 32, q[dd], o);
+        }
+        store32(a.out + row * ldo + h * 32, o);
+        store32(a.qt_out + row * ldo + h * 32, q);
+    } else {
+        const float* dcx = dctx + h * 1024;
+        float g[32], t[32], dq[32];
+        load32(a.dout + row * ldo + h * 32, g);
+        load32(a.qt + row * ldo + h * 32, t);               // Qt = scale * sigma
+        float dot = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 32; ++dd) { dq[dd] = lds_dot32(cx + dd * 32, g); dot += t[dd] * dq[dd]; }
+        const float inv_scale = 1.0f / a.scale;
+#pragma unroll
+        for (int dd = 0; dd < 32; ++dd) dq[dd] = t[dd] * (dq[dd] - dot * inv_scale);
+        store32(a.out + row * ld + h * 32, dq);
+        float k[32], v[32], dv[32];
+        load32(a.qkv + row * ld + (H + h) * 32, k);
+        load32(a.qkv + row * ld + (2 * H + h) * 32, v);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) dv[e] = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 32; ++dd) {
+            const float kt = __expf(k[dd] - mx[h * 32 + dd]) * zinv[h * 32 + dd];
+            const float dkt = lds_dot32(dcx + dd * 32, v);
+            lds_axpy32(dcx + dd * 32, kt, dv);
+            k[dd] = kt * (dkt - sd[h * 32 + dd]);
+        }
+        store32(a.out + row * ld + (H + h) * 32, k);
+        store32(a.out + row * ld + (2 * H + h) * 32, dv);
+    }
+}
+
+int sla_shape_check(int frames, int n, int heads) {
+    if (frames <= 0 || n <= 0 || heads <= 0 || heads > 8 || 256 % heads) return VDMI_E_SHAPE;
+    if ((long long)frames * n > 0x7fffffffLL || frames > 65535) return VDMI_E_SHAPE;
+    return VDMI_OK;
+}
+
+}   // namespace
+
+extern "C" size_t vdmi_sla_train_partial_bytes(int frames, int n, int heads) {
+    if (sla_shape_check(frames, n, heads) != VDMI_OK) return 0;
+    const size_t nsplit = (size_t)(n + SLA_SPLIT - 1) / SLA_SPLIT;
+    return (size_t)frames * heads * nsplit * SLA_PART * sizeof(float);
+}
+
+// mode 0: partial sums of softmax_n(a)-weighted b with the running maximum and weight sum (a = k columns, b = v columns);
+// mode 1: plain partial sums of a[n][d] * b[n][e] (a = Qt rows, b = gradient of out)
+extern "C" int vdmi_sla_train_reduce(const void* a, int lda, const void* b, int ldb, void* partials, int frames, int n,
+                                     int heads, int mode, vdmi_stream stream) {
+    if (!a || !b || !partials) return VDMI_E_ARG;
+    const int st = sla_shape_check(frames, n, heads);
+    if (st != VDMI_OK) return st;
+    if (lda % 8 || ldb % 8 || lda < heads * 32 || ldb < heads * 32 || (mode != 0 && mode != 1)) return VDMI_E_SHAPE;
+    if (!aligned16(a) || !aligned16(b) || !aligned16(partials)) return VDMI_E_ALIGN;
+    SlaRedArgs r{static_cast<const __bf16*>(a), lda, static_cast<const __bf16*>(b), ldb, static_cast<float*>(partials), n, heads,
+                 (n + SLA_SPLIT - 1) / SLA_SPLIT};
+    const dim3 grid((unsigned)r.nsplit, (unsigned)heads, (unsigned)frames);
+    if (mode == 0) hipLaunchKernelGGL(sla_reduce_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), r);
+    else hipLaunchKernelGGL(sla_reduce_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), r);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+static int sla_rows_launch(bool bwd, SlaRowsArgs& r, hipStream_t stream) {
+    const int st = sla_shape_check(r.frames, r.n, r.heads);
+    if (st != VDMI_OK) return st;
+    r.nsplit = (r.n + SLA_SPLIT - 1) / SLA_SPLIT;
+    const int rb = 256 / r.heads;
+    const size_t lds = (size_t)r.heads * 1024 * 4 * (bwd ? 2 : 1) + (bwd ? (size_t)3 * r.heads * 32 * 4 : 0);
+    const dim3 grid((unsigned)((r.n + rb - 1) / rb), (unsigned)r.frames);
+    static std::atomic<uint64_t> mask_f{0}, mask_b{0};
+    if (bwd) {
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(sla_rows_kernel<true>), mask_b, 96 * 1024)) return VDMI_E_LAUNCH;
+        hipLaunchKernelGGL(sla_rows_kernel<true>, grid, dim3(256), lds, stream, r);
+    } else {
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(sla_rows_kernel<false>), mask_f, 96 * 1024)) return VDMI_E_LAUNCH;
+        hipLaunchKernelGGL(sla_rows_kernel<false>, grid, dim3(256), lds, stream, r);
+    }
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" int vdmi_sla_train_rows_fwd(const void* qkv, const void* part_ctx, void* out, void* qt, int frames, int n,
+                                       int heads, float scale, vdmi_stream stream) {
+    if (!qkv || !part_ctx || !out || !qt) return VDMI_E_ARG;
+    if (!aligned16(qkv) || !aligned16(out) || !aligned16(qt)) return VDMI_E_ALIGN;
+    SlaRowsArgs r{};
+    r.qkv = static_cast<const __bf16*>(qkv);
+    r.part_ctx = static_cast<const float*>(part_ctx);
+    r.out = static_cast<__bf16*>(out);
+    r.qt_out = static_cast<__bf16*>(qt);
+    r.n = n; r.heads = heads; r.frames = frames; r.scale = scale;
+    return sla_rows_launch(false, r, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vdmi_sla_train_rows_bwd(const void* qkv, const void* qt, const void* dout, const void* part_ctx,
+                                       const void* part_dctx, void* dqkv, int frames, int n, int heads, float scale,
+                                       vdmi_stream stream) {
+    if (!qkv || !qt || !dout || !part_ctx || !part_dctx || !dqkv) return VDMI_E_ARG;
+    if (!aligned16(qkv) || !aligned16(qt) || !aligned16(dout) || !aligned16(dqkv)) return VDMI_E_ALIGN;
+    SlaRowsArgs r{};
+    r.qkv = static_cast<const __bf16*>(qkv);
+    r.qt = static_cast<const __bf16*>(qt);
+    r.dout = static_cast<const __bf16*>(dout);
+    r.part_ctx = static_cast<const float*>(part_ctx);
+    r.part_dctx = static_cast<const float*>(part_dctx);
+    r.out = static_cast<__bf16*>(dqkv);
+    r.n = n; r.heads = heads; r.frames = frames; r.scale = scale;
+    return sla_rows_launch(true, r, static_cast<hipStream_t>(stream));
+}

@@ -524,3 +524,81 @@ def resample(mod, x: torch.Tensor) -> torch.Tensor:
     if isinstance(mod, torch.nn.Conv3d) and (mod.kernel_size, mod.stride, mod.padding) == (k, st, pd):
         return DownsampleFn.apply(x, mod.weight, mod.bias)
     return mod(x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Residual(PreNorm(SpatialLinearAttention)), vdp.py:454-479
+# ---------------------------------------------------------------------------------------------------------------------
+def _sla_partials(frames, n, heads, device):
+    return torch.empty(_lib.lib().vdmi_sla_train_partial_bytes(frames, n, heads), device=device, dtype=torch.uint8)
+
+
+class SlaFn(torch.autograd.Function):
+    """x float (B, C, F, H, W); gamma (1, C, 1, 1, 1); wqkv (3*heads*32, C, 1, 1) without bias; wout (C, heads*32, 1, 1),
+    bout (C).  Forward and backward on the HIP kernels."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, gamma, wqkv, wout, bout, heads, scale, eps):
+        if not x.is_cuda:
+            raise _lib.VdmiError("the HIP training backend needs CUDA (HIP) tensors; there is no CPU path")
+        lib = _lib.lib()
+        b, c, f, h, w = x.shape
+        n, frames, hid = h * w, b * f, heads * 32
+        rows = frames * n
+        xr = to_rows(x)
+        xh = torch.empty_like(xr)
+        check(lib.vdmi_layernorm_rows(xr.data_ptr(), xh.data_ptr(), rows, c, eps, _stream()), "vdmi_layernorm_rows")
+        wq2, wo2 = wqkv.detach().reshape(3 * hid, c), wout.detach().reshape(c, hid)
+        wp = (wq2 * gamma.detach().reshape(1, c)).contiguous()
+        qkv = conv_rows(xh, _linear_pack(wp, False), None, frames, f, h, w)
+        p_ctx = _sla_partials(frames, n, heads, x.device)
+        base = qkv.data_ptr()
+        check(lib.vdmi_sla_train_reduce(base + 2 * hid, 3 * hid, base + 4 * hid, 3 * hid, p_ctx.data_ptr(), frames, n, heads, 0,
+                                        _stream()), "vdmi_sla_train_reduce")
+        out = torch.empty(rows, hid, device=x.device, dtype=torch.bfloat16)
+        qt = torch.empty_like(out)
+        check(lib.vdmi_sla_train_rows_fwd(qkv.data_ptr(), p_ctx.data_ptr(), out.data_ptr(), qt.data_ptr(), frames, n, heads,
+                                          scale, _stream()), "vdmi_sla_train_rows_fwd")
+        y = conv_rows(out, _linear_pack(wo2.contiguous(), False), bout.detach().float().contiguous(), frames, f, h, w,
+                      residual=xr)
+        ctx.save_for_backward(xr, xh, qkv, qt, out, p_ctx, wp, wqkv, wout, gamma)
+        ctx.meta = (b, c, f, h, w, heads, scale, eps)
+        return from_rows(y, b, f, h, w)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        xr, xh, qkv, qt, out, p_ctx, wp, wqkv, wout, gamma = ctx.saved_tensors
+        b, c, f, h, w, heads, scale, eps = ctx.meta
+        lib = _lib.lib()
+        n, frames, hid = h * w, b * f, heads * 32
+        rows = frames * n
+        dyr = to_rows(dy)
+        wo2 = wout.detach().reshape(c, hid).contiguous()
+        do = conv_rows(dyr, _linear_pack(wo2, True), None, frames, f, h, w)
+        dwout = conv_wgrad(rows_transposed(out, frames, n), rows_transposed(dyr, frames, n), hid, c, frames, h, w, 1)
+        p_dctx = _sla_partials(frames, n, heads, dy.device)
+        check(lib.vdmi_sla_train_reduce(qt.data_ptr(), hid, do.data_ptr(), hid, p_dctx.data_ptr(), frames, n, heads, 1,
+                                        _stream()), "vdmi_sla_train_reduce")
+        dqkv = torch.empty_like(qkv)
+        check(lib.vdmi_sla_train_rows_bwd(qkv.data_ptr(), qt.data_ptr(), do.data_ptr(), p_ctx.data_ptr(), p_dctx.data_ptr(),
+                                          dqkv.data_ptr(), frames, n, heads, scale, _stream()), "vdmi_sla_train_rows_bwd")
+        dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
+        dwp = conv_wgrad(rows_transposed(xh, frames, n), rows_transposed(dqkv, frames, n), c, 3 * hid, frames, h, w,
+                         1).reshape(3 * hid, c)
+        dwqkv = (dwp * gamma.detach().reshape(1, c)).reshape(wqkv.shape)
+        dgamma = (dwp * wqkv.detach().reshape(3 * hid, c)).sum(0).reshape(gamma.shape)
+        dx = torch.empty_like(xr)
+        check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
+                                          _stream()), "vdmi_layernorm_rows_bwd")
+        return from_rows(dx, b, f, h, w), dgamma, dwqkv, dwout.reshape(wout.shape), colsum_rows(dyr), None, None, None
+
+
+def spatial_linear_attention(res, x: torch.Tensor) -> torch.Tensor:
+    """autograd.py's `_linear_attention` (the SpatialLinearAttention form) on the HIP kernels."""
+    sl = res.fn.fn
+    if sl.dim_head != 32 or sl.to_qkv.bias is not None:
+        raise _lib.VdmiError("the HIP linear attention takes heads of 32 features and a to_qkv without bias")
+    return SlaFn.apply(x, res.fn.norm.gamma, sl.to_qkv.weight, sl.to_out.weight, sl.to_out.bias, sl.heads, float(sl.scale),
+                       float(res.fn.norm.eps))
