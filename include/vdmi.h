@@ -476,21 +476,26 @@ int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* dout, const 
  * to_qkv: qkv bf16 [frames*n][3*heads*32] (q | k | v, column = head*32 + feature, row = frame*n + position), heads of 32
  * features, heads in {1, 2, 4, 8}.  Per (frame, head): Kt = softmax of k over the n positions, Qt = softmax of q over the
  * 32 features times scale, ctx = Kt^T v (32 x 32), out = Qt ctx.
- *   vdmi_sla_train_reduce   sums over the positions, left as per-split partials (vdmi_sla_train_partial_bytes() bytes):
- *                           mode 0: a = the k columns, b = the v columns  -> ctx (with the softmax's maximum / weight sum);
- *                           mode 1: a = the saved Qt rows, b = the gradient of out  -> the gradient of ctx
- *   vdmi_sla_train_rows_fwd out rows and Qt rows [frames*n][heads*32] from qkv and the mode-0 partials
- *   vdmi_sla_train_rows_bwd gradient of the raw qkv rows from qkv, Qt, the gradient of out and both partials
+ *   vdmi_sla_train_reduce   sums over the positions (per-split partials in `partials`, scratch of
+ *                           vdmi_sla_train_partial_bytes() bytes, then one combined record per (frame, head) in
+ *                           `combined`, vdmi_sla_train_combined_bytes() bytes):
+ *                           mode 0: a = the k columns, b = the v columns  -> ctx with the softmax's maximum / weight sum;
+ *                           mode 1: a = the saved Qt rows, b = the gradient of out, combined_ctx = the mode-0 record
+ *                                   -> the gradient of ctx and S[d] = sum_e dctx[d][e] ctx[d][e]
+ *   vdmi_sla_train_rows_fwd out rows and Qt rows [frames*n][heads*32] from qkv and the mode-0 record
+ *   vdmi_sla_train_rows_bwd gradient of the raw qkv rows from qkv, Qt, the gradient of out and both records
  * The projections around them (to_qkv, to_out + bias + residual) and their gradients are vdmi_tapgemm / vdmi_conv_wgrad /
  * vdmi_colsum, the LayerNorm vdmi_layernorm_rows.
  * ------------------------------------------------------------------------------------------ */
 size_t vdmi_sla_train_partial_bytes(int frames, int n, int heads);                         /* HOST */
-int vdmi_sla_train_reduce(const void* a, int lda, const void* b, int ldb, void* partials, int frames, int n, int heads,
-                          int mode, vdmi_stream stream);
-int vdmi_sla_train_rows_fwd(const void* qkv, const void* part_ctx, void* out, void* qt, int frames, int n, int heads,
+size_t vdmi_sla_train_combined_bytes(int frames, int heads);                               /* HOST */
+int vdmi_sla_train_reduce(const void* a, int lda, const void* b, int ldb, void* partials, const void* combined_ctx,
+                          void* combined, int frames, int n, int heads, int mode, vdmi_stream stream);
+int vdmi_sla_train_rows_fwd(const void* qkv, const void* combined_ctx, void* out, void* qt, int frames, int n, int heads,
                             float scale, vdmi_stream stream);
-int vdmi_sla_train_rows_bwd(const void* qkv, const void* qt, const void* dout, const void* part_ctx, const void* part_dctx,
-                            void* dqkv, int frames, int n, int heads, float scale, vdmi_stream stream);
+int vdmi_sla_train_rows_bwd(const void* qkv, const void* qt, const void* dout, const void* combined_ctx,
+                            const void* combined_dctx, void* dqkv, int frames, int n, int heads, float scale,
+                            vdmi_stream stream);
 
 #ifdef __cplusplus
 }

@@ -376,7 +376,7 @@ def test_resampling_convs_forward_backward_vs_torch(c, f, h, w):
         assert record(tag + ".db", rel_err(mod.bias.grad, ref[3]), 1e-2) < 1e-2
 
 
-@pytest.mark.parametrize("frames,n,heads", [(3, 100, 4), (2, 2500, 4), (5, 64, 8)])
+@pytest.mark.parametrize("frames,n,heads", [(3, 100, 4), (2, 2500, 4), (5, 64, 8), (16, 4096, 4)])
 def test_sla_core_forward_backward_vs_torch(frames, n, heads):
     """The linear-attention core (vdp.py:467-477) on raw q, k, v rows: reduction partials + row kernels against torch."""
     from video_diffusion_amd import _lib
@@ -385,16 +385,14 @@ def test_sla_core_forward_backward_vs_torch(frames, n, heads):
     rows, hid, scale = frames * n, heads * 32, 32 ** -0.5
     qkv = _bf(torch.randn(rows, 3 * hid, generator=g) * 1.5).to(DEV)
     dout = _bf(torch.randn(rows, hid, generator=g)).to(DEV)
-    nbytes = lib.vdmi_sla_train_partial_bytes(frames, n, heads)
-    p_ctx = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    p_dctx = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    from video_diffusion_amd import train_hip as T
     base = qkv.data_ptr()
-    _lib.check(lib.vdmi_sla_train_reduce(base + 2 * hid, 3 * hid, base + 4 * hid, 3 * hid, p_ctx.data_ptr(), frames, n, heads, 0, None))
+    c_ctx = T._sla_reduce(base + 2 * hid, 3 * hid, base + 4 * hid, 3 * hid, None, frames, n, heads, 0, DEV)
     out, qt, dqkv = (torch.empty(rows, hid, device=DEV, dtype=torch.bfloat16), torch.empty(rows, hid, device=DEV, dtype=torch.bfloat16),
                      torch.empty_like(qkv))
-    _lib.check(lib.vdmi_sla_train_rows_fwd(qkv.data_ptr(), p_ctx.data_ptr(), out.data_ptr(), qt.data_ptr(), frames, n, heads, scale, None))
-    _lib.check(lib.vdmi_sla_train_reduce(qt.data_ptr(), hid, dout.data_ptr(), hid, p_dctx.data_ptr(), frames, n, heads, 1, None))
-    _lib.check(lib.vdmi_sla_train_rows_bwd(qkv.data_ptr(), qt.data_ptr(), dout.data_ptr(), p_ctx.data_ptr(), p_dctx.data_ptr(),
+    _lib.check(lib.vdmi_sla_train_rows_fwd(qkv.data_ptr(), c_ctx.data_ptr(), out.data_ptr(), qt.data_ptr(), frames, n, heads, scale, None))
+    c_dctx = T._sla_reduce(qt.data_ptr(), hid, dout.data_ptr(), hid, c_ctx, frames, n, heads, 1, DEV)
+    _lib.check(lib.vdmi_sla_train_rows_bwd(qkv.data_ptr(), qt.data_ptr(), dout.data_ptr(), c_ctx.data_ptr(), c_dctx.data_ptr(),
                                            dqkv.data_ptr(), frames, n, heads, scale, None))
     qr = qkv.double().requires_grad_(True)
     t = qr.view(frames, n, 3, heads, 32).permute(2, 0, 3, 4, 1)            # [3][frames][heads][32][n]

@@ -150,7 +150,9 @@ _SIGNATURES = {
     "vdmi_tattn_core_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "vdmi_tattn_core_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "vdmi_sla_train_partial_bytes": (C.c_size_t, [C.c_int] * 3),
-    "vdmi_sla_train_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "vdmi_sla_train_combined_bytes": (C.c_size_t, [C.c_int] * 2),
+    "vdmi_sla_train_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] +
+                              [C.c_int] * 4 + [C.c_void_p]),
     "vdmi_sla_train_rows_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "vdmi_sla_train_rows_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
 }

@@ -463,15 +463,64 @@ __global__ __launch_bounds__(256) void sla_reduce_kernel(const SlaRedArgs a) {
     if ((tid & 7) == 0) { out[1024 + d] = m; out[1056 + d] = z; }
 }
 
+constexpr int SLA_COMB = 32 * 32 + 64;        // floats per combined (frame, head): mode 0: ctx [32][32], max [32], 1 / weight sum [32]
+                                              //                                      mode 1: dctx [32][32], S [32], unused [32]
+
+// one workgroup per (head, frame): the partials of all splits -> one combined record
+struct SlaCombArgs {
+    const float* part;
+    const float* comb_ctx;    // mode 1: the mode-0 record (S = sum_e dctx * ctx)
+    float* comb;
+    int heads, nsplit, mode;
+};
+
+__global__ __launch_bounds__(256) void sla_combine_kernel(const SlaCombArgs a) {
+    __shared__ float tile[1024];
+    const int head = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const long long fh = (long long)frame * a.heads + head;
+    const float* p = a.part + fh * a.nsplit * SLA_PART;
+    float* out = a.comb + fh * SLA_COMB;
+    for (int i = tid; i < 1024; i += 256) {
+        const int dd = i >> 5;
+        float v;
+        if (a.mode == 0) {
+            float M = -1e30f;
+            for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, p[s * SLA_PART + 1024 + dd]);
+            float num = 0.f, den = 0.f;
+            for (int s = 0; s < a.nsplit; ++s) {
+                const float w = __expf(p[s * SLA_PART + 1024 + dd] - M);
+                num += p[s * SLA_PART + i] * w;
+                den += p[s * SLA_PART + 1056 + dd] * w;
+            }
+            v = num / den;
+            if ((i & 31) == 0) { out[1024 + dd] = M; out[1056 + dd] = 1.0f / den; }
+        } else {
+            v = 0.f;
+            for (int s = 0; s < a.nsplit; ++s) v += p[s * SLA_PART + i];
+            tile[i] = v * a.comb_ctx[fh * SLA_COMB + i];
+        }
+        out[i] = v;
+    }
+    if (a.mode == 1) {
+        __syncthreads();
+        if (tid < 32) {
+            float sacc = 0.f;
+            for (int e = 0; e < 32; ++e) sacc += tile[tid * 32 + e];
+            out[1024 + tid] = sacc;
+            out[1056 + tid] = 0.f;
+        }
+    }
+}
+
 struct SlaRowsArgs {
     const __bf16* qkv;        // [rows][3*heads*32]
     const __bf16* qt;         // bwd: saved Qt rows [rows][heads*32]
     const __bf16* dout;       // bwd: gradient of out [rows][heads*32]
-    const float* part_ctx;    // partials of the softmax reduction (k, v)
-    const float* part_dctx;   // bwd: partials of the plain reduction (Qt, dout)
+    const float* comb_ctx;    // combined records of the softmax reduction (k, v)
+    const float* comb_dctx;   // bwd: combined records of the plain reduction (Qt, dout)
     __bf16* out;              // fwd: out rows [rows][heads*32]; bwd: dqkv rows [rows][3*heads*32]
     __bf16* qt_out;           // fwd: Qt rows
-    int n, heads, nsplit, frames;
+    int n, heads, frames, blocks_per_wg;
     float scale;
 };
 
@@ -479,95 +528,70 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void sla_rows_kernel(const SlaRowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.heads, tid = threadIdx.x;
-    float* ctx = reinterpret_cast<float*>(smem);          // [H][32][32]
-    float* dctx = ctx + H * 1024;                         // bwd: [H][32][32]
-    float* mx = dctx + (BWD ? H * 1024 : 0);              // bwd: [H][32] max, then 1 / weight sum, then S
-    float* zinv = mx + H * 32;
-    float* sd = zinv + H * 32;
+    float* c0 = reinterpret_cast<float*>(smem);           // [H][SLA_COMB]: ctx, max, 1 / weight sum
+    float* c1 = c0 + H * SLA_COMB;                        // bwd: [H][SLA_COMB]: dctx, S
     const int frame = blockIdx.y;
-    // ---- combine the partials of this frame ------------------------------------------------------------------------
-    for (int i = tid; i < H * 1024; i += 256) {
-        const int h = i >> 10, dd = (i >> 5) & 31, e = i & 31;
-        const float* p = a.part_ctx + ((long long)frame * H + h) * a.nsplit * SLA_PART;
-        float M = -1e30f;
-        for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, p[s * SLA_PART + 1024 + dd]);
-        float num = 0.f, den = 0.f;
-        for (int s = 0; s < a.nsplit; ++s) {
-            const float w = __expf(p[s * SLA_PART + 1024 + dd] - M);
-            num += p[s * SLA_PART + dd * 32 + e] * w;
-            den += p[s * SLA_PART + 1056 + dd] * w;
-        }
-        ctx[i] = num / den;
-        if constexpr (BWD) {
-            if (e == 0) { mx[h * 32 + dd] = M; zinv[h * 32 + dd] = 1.0f / den; }
-            const float* q = a.part_dctx + ((long long)frame * H + h) * a.nsplit * SLA_PART;
-            float sum = 0.f;
-            for (int s = 0; s < a.nsplit; ++s) sum += q[s * SLA_PART + dd * 32 + e];
-            dctx[i] = sum;
-        }
+    for (int i = tid; i < H * SLA_COMB; i += 256) {
+        c0[i] = a.comb_ctx[(long long)frame * H * SLA_COMB + i];
+        if constexpr (BWD) c1[i] = a.comb_dctx[(long long)frame * H * SLA_COMB + i];
     }
     __syncthreads();
-    if constexpr (BWD) {
-        for (int i = tid; i < H * 32; i += 256) {
-            float s = 0.f;
-            for (int e = 0; e < 32; ++e) s += dctx[i * 32 + e] * ctx[i * 32 + e];
-            sd[i] = s;
-        }
-        __syncthreads();
-    }
-    // ---- rows: thread = (head, row of the block); a wave's lanes share the head --------------------------------------
+    // rows: thread = (head, row of the block); a wave's lanes share the head
     const int rb = 256 / H, h = tid / rb, r = tid - h * rb;
-    const int pos = blockIdx.x * rb + r;
-    if (h >= H || pos >= a.n) return;
-    const long long row = (long long)frame * a.n + pos;
+    if (h >= H) return;
     const int ld = 3 * H * 32, ldo = H * 32;
-    const float* cx = ctx + h * 1024;
-    if constexpr (!BWD) {
-        float q[32];
-        load32(a.qkv + row * ld + h * 32, q);
-        float m = q[0];
+    const float* cx = c0 + h * SLA_COMB;
+    for (int blk = 0; blk < a.blocks_per_wg; ++blk) {
+        const int pos = (blockIdx.x * a.blocks_per_wg + blk) * rb + r;
+        if (pos >= a.n) break;
+        const long long row = (long long)frame * a.n + pos;
+        if constexpr (!BWD) {
+            float q[32];
+            load32(a.qkv + row * ld + h * 32, q);
+            float m = q[0];
 #pragma unroll
-        for (int dd = 1; dd < 32; ++dd) m = fmaxf(m, q[dd]);
-        float l = 0.f;
+            for (int dd = 1; dd < 32; ++dd) m = fmaxf(m, q[dd]);
+            float l = 0.f;
 #pragma unroll
-        for (int dd = 0; dd < 32; ++dd) { q[dd] = __expf(q[dd] - m); l += q[dd]; }
-        const float inv = a.scale / l;
-        float o[32];
+            for (int dd = 0; dd < 32; ++dd) { q[dd] = __expf(q[dd] - m); l += q[dd]; }
+            const float inv = a.scale / l;
+            float o[32];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) o[e] = 0.f;
+            for (int e = 0; e < 32; ++e) o[e] = 0.f;
 #pragma unroll
-        for (int dd = 0; dd < 32; ++dd) {
-            q[dd] *= inv;
-            lds_axpy32(cx + dd * 32, q[dd], o);
+            for (int dd = 0; dd < 32; ++dd) {
+                q[dd] *= inv;
+                lds_axpy32(cx + dd * 32, q[dd], o);
+            }
+            store32(a.out + row * ldo + h * 32, o);
+            store32(a.qt_out + row * ldo + h * 32, q);
+        } else {
+            const float* dcx = c1 + h * SLA_COMB;
+            float g[32], t[32], dq[32];
+            load32(a.dout + row * ldo + h * 32, g);
+            load32(a.qt + row * ldo + h * 32, t);               // Qt = scale * sigma
+            float dot = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < 32; ++dd) { dq[dd] = lds_dot32(cx + dd * 32, g); dot += t[dd] * dq[dd]; }
+            const float inv_scale = 1.0f / a.scale;
+#pragma unroll
+            for (int dd = 0; dd < 32; ++dd) dq[dd] = t[dd] * (dq[dd] - dot * inv_scale);
+            store32(a.out + row * ld + h * 32, dq);
+            float k[32], v[32], dv[32];
+            load32(a.qkv + row * ld + (H + h) * 32, k);
+            load32(a.qkv + row * ld + (2 * H + h) * 32, v);
+#pragma unroll
+            for (int e = 0; e < 32; ++e) dv[e] = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < 32; ++dd) {
+                const float kt = __expf(k[dd] - cx[1024 + dd]) * cx[1056 + dd];
+                const float dkt = lds_dot32(dcx + dd * 32, v);
+                lds_axpy32(dcx + dd * 32, kt, dv);
+                k[dd] = kt * (dkt - dcx[1024 + dd]);
+            }
+            store32(a.out + row * ld + (H + h) * 32, k);
+            store32(a.out + row * ld + (2 * H + h) * 32, dv);
         }
-        store32(a.out + row * ldo + h * 32, o);
-        store32(a.qt_out + row * ldo + h * 32, q);
-    } else {
-        const float* dcx = dctx + h * 1024;
-        float g[32], t[32], dq[32];
-        load32(a.dout + row * ldo + h * 32, g);
-        load32(a.qt + row * ldo + h * 32, t);               // Qt = scale * sigma
-        float dot = 0.f;
-#pragma unroll
-        for (int dd = 0; dd < 32; ++dd) { dq[dd] = lds_dot32(cx + dd * 32, g); dot += t[dd] * dq[dd]; }
-        const float inv_scale = 1.0f / a.scale;
-#pragma unroll
-        for (int dd = 0; dd < 32; ++dd) dq[dd] = t[dd] * (dq[dd] - dot * inv_scale);
-        store32(a.out + row * ld + h * 32, dq);
-        float k[32], v[32], dv[32];
-        load32(a.qkv + row * ld + (H + h) * 32, k);
-        load32(a.qkv + row * ld + (2 * H + h) * 32, v);
-#pragma unroll
-        for (int e = 0; e < 32; ++e) dv[e] = 0.f;
-#pragma unroll
-        for (int dd = 0; dd < 32; ++dd) {
-            const float kt = __expf(k[dd] - mx[h * 32 + dd]) * zinv[h * 32 + dd];
-            const float dkt = lds_dot32(dcx + dd * 32, v);
-            lds_axpy32(dcx + dd * 32, kt, dv);
-            k[dd] = kt * (dkt - sd[h * 32 + dd]);
-        }
-        store32(a.out + row * ld + (H + h) * 32, k);
-        store32(a.out + row * ld + (2 * H + h) * 32, dv);
     }
 }
 
@@ -585,20 +609,32 @@ extern "C" size_t vdmi_sla_train_partial_bytes(int frames, int n, int heads) {
     return (size_t)frames * heads * nsplit * SLA_PART * sizeof(float);
 }
 
-// mode 0: partial sums of softmax_n(a)-weighted b with the running maximum and weight sum (a = k columns, b = v columns);
-// mode 1: plain partial sums of a[n][d] * b[n][e] (a = Qt rows, b = gradient of out)
-extern "C" int vdmi_sla_train_reduce(const void* a, int lda, const void* b, int ldb, void* partials, int frames, int n,
-                                     int heads, int mode, vdmi_stream stream) {
-    if (!a || !b || !partials) return VDMI_E_ARG;
+extern "C" size_t vdmi_sla_train_combined_bytes(int frames, int heads) {
+    if (frames <= 0 || heads <= 0) return 0;
+    return (size_t)frames * heads * SLA_COMB * sizeof(float);
+}
+
+// mode 0: softmax_n(a)-weighted sums of b (a = k columns, b = v columns) -> combined = ctx, the softmax's maximum and
+//         1 / weight sum per feature;
+// mode 1: plain sums of a[n][d] * b[n][e] (a = Qt rows, b = gradient of out) -> combined = dctx and S[d] = sum_e dctx*ctx
+//         (combined_ctx = the mode-0 record).  `partials` is scratch.
+extern "C" int vdmi_sla_train_reduce(const void* a, int lda, const void* b, int ldb, void* partials, const void* combined_ctx,
+                                     void* combined, int frames, int n, int heads, int mode, vdmi_stream stream) {
+    if (!a || !b || !partials || !combined || (mode == 1 && !combined_ctx)) return VDMI_E_ARG;
     const int st = sla_shape_check(frames, n, heads);
     if (st != VDMI_OK) return st;
     if (lda % 8 || ldb % 8 || lda < heads * 32 || ldb < heads * 32 || (mode != 0 && mode != 1)) return VDMI_E_SHAPE;
     if (!aligned16(a) || !aligned16(b) || !aligned16(partials)) return VDMI_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     SlaRedArgs r{static_cast<const __bf16*>(a), lda, static_cast<const __bf16*>(b), ldb, static_cast<float*>(partials), n, heads,
                  (n + SLA_SPLIT - 1) / SLA_SPLIT};
     const dim3 grid((unsigned)r.nsplit, (unsigned)heads, (unsigned)frames);
-    if (mode == 0) hipLaunchKernelGGL(sla_reduce_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), r);
-    else hipLaunchKernelGGL(sla_reduce_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), r);
+    if (mode == 0) hipLaunchKernelGGL(sla_reduce_kernel<true>, grid, dim3(256), 0, s, r);
+    else hipLaunchKernelGGL(sla_reduce_kernel<false>, grid, dim3(256), 0, s, r);
+    VDMI_LAUNCH_CHECK();
+    SlaCombArgs c{static_cast<const float*>(partials), static_cast<const float*>(combined_ctx), static_cast<float*>(combined),
+                  heads, r.nsplit, mode};
+    hipLaunchKernelGGL(sla_combine_kernel, dim3((unsigned)heads, (unsigned)frames), dim3(256), 0, s, c);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
@@ -606,10 +642,13 @@ extern "C" int vdmi_sla_train_reduce(const void* a, int lda, const void* b, int 
 static int sla_rows_launch(bool bwd, SlaRowsArgs& r, hipStream_t stream) {
     const int st = sla_shape_check(r.frames, r.n, r.heads);
     if (st != VDMI_OK) return st;
-    r.nsplit = (r.n + SLA_SPLIT - 1) / SLA_SPLIT;
     const int rb = 256 / r.heads;
-    const size_t lds = (size_t)r.heads * 1024 * 4 * (bwd ? 2 : 1) + (bwd ? (size_t)3 * r.heads * 32 * 4 : 0);
-    const dim3 grid((unsigned)((r.n + rb - 1) / rb), (unsigned)r.frames);
+    const int blocks = (r.n + rb - 1) / rb;
+    // each workgroup first copies its frame's combined records (4-9 KB per head) into LDS: several row blocks per workgroup
+    // once the frame has enough of them to fill the device anyway
+    r.blocks_per_wg = blocks * r.frames >= 4096 ? 8 : (blocks * r.frames >= 1024 ? 2 : 1);
+    const size_t lds = (size_t)r.heads * SLA_COMB * 4 * (bwd ? 2 : 1);
+    const dim3 grid((unsigned)((blocks + r.blocks_per_wg - 1) / r.blocks_per_wg), (unsigned)r.frames);
     static std::atomic<uint64_t> mask_f{0}, mask_b{0};
     if (bwd) {
         if (vdmi_set_max_lds(reinterpret_cast<const void*>(sla_rows_kernel<true>), mask_b, 96 * 1024)) return VDMI_E_LAUNCH;
@@ -622,30 +661,30 @@ static int sla_rows_launch(bool bwd, SlaRowsArgs& r, hipStream_t stream) {
     return VDMI_OK;
 }
 
-extern "C" int vdmi_sla_train_rows_fwd(const void* qkv, const void* part_ctx, void* out, void* qt, int frames, int n,
+extern "C" int vdmi_sla_train_rows_fwd(const void* qkv, const void* combined_ctx, void* out, void* qt, int frames, int n,
                                        int heads, float scale, vdmi_stream stream) {
-    if (!qkv || !part_ctx || !out || !qt) return VDMI_E_ARG;
+    if (!qkv || !combined_ctx || !out || !qt) return VDMI_E_ARG;
     if (!aligned16(qkv) || !aligned16(out) || !aligned16(qt)) return VDMI_E_ALIGN;
     SlaRowsArgs r{};
     r.qkv = static_cast<const __bf16*>(qkv);
-    r.part_ctx = static_cast<const float*>(part_ctx);
+    r.comb_ctx = static_cast<const float*>(combined_ctx);
     r.out = static_cast<__bf16*>(out);
     r.qt_out = static_cast<__bf16*>(qt);
     r.n = n; r.heads = heads; r.frames = frames; r.scale = scale;
     return sla_rows_launch(false, r, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int vdmi_sla_train_rows_bwd(const void* qkv, const void* qt, const void* dout, const void* part_ctx,
-                                       const void* part_dctx, void* dqkv, int frames, int n, int heads, float scale,
+extern "C" int vdmi_sla_train_rows_bwd(const void* qkv, const void* qt, const void* dout, const void* combined_ctx,
+                                       const void* combined_dctx, void* dqkv, int frames, int n, int heads, float scale,
                                        vdmi_stream stream) {
-    if (!qkv || !qt || !dout || !part_ctx || !part_dctx || !dqkv) return VDMI_E_ARG;
+    if (!qkv || !qt || !dout || !combined_ctx || !combined_dctx || !dqkv) return VDMI_E_ARG;
     if (!aligned16(qkv) || !aligned16(qt) || !aligned16(dout) || !aligned16(dqkv)) return VDMI_E_ALIGN;
     SlaRowsArgs r{};
     r.qkv = static_cast<const __bf16*>(qkv);
     r.qt = static_cast<const __bf16*>(qt);
     r.dout = static_cast<const __bf16*>(dout);
-    r.part_ctx = static_cast<const float*>(part_ctx);
-    r.part_dctx = static_cast<const float*>(part_dctx);
+    r.comb_ctx = static_cast<const float*>(combined_ctx);
+    r.comb_dctx = static_cast<const float*>(combined_dctx);
     r.out = static_cast<__bf16*>(dqkv);
     r.n = n; r.heads = heads; r.frames = frames; r.scale = scale;
     return sla_rows_launch(true, r, static_cast<hipStream_t>(stream));

@@ -529,8 +529,14 @@ def resample(mod, x: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------------------
 # Residual(PreNorm(SpatialLinearAttention)), vdp.py:454-479
 # ---------------------------------------------------------------------------------------------------------------------
-def _sla_partials(frames, n, heads, device):
-    return torch.empty(_lib.lib().vdmi_sla_train_partial_bytes(frames, n, heads), device=device, dtype=torch.uint8)
+def _sla_reduce(a_ptr, lda, b_ptr, ldb, comb_ctx, frames, n, heads, mode, device):
+    """Sums over the positions -> one combined record per (frame, head) (float tensor)."""
+    lib = _lib.lib()
+    scratch = torch.empty(lib.vdmi_sla_train_partial_bytes(frames, n, heads), device=device, dtype=torch.uint8)
+    comb = torch.empty(lib.vdmi_sla_train_combined_bytes(frames, heads) // 4, device=device, dtype=torch.float32)
+    check(lib.vdmi_sla_train_reduce(a_ptr, lda, b_ptr, ldb, scratch.data_ptr(), None if comb_ctx is None else comb_ctx.data_ptr(),
+                                    comb.data_ptr(), frames, n, heads, mode, _stream()), "vdmi_sla_train_reduce")
+    return comb
 
 
 class SlaFn(torch.autograd.Function):
@@ -552,10 +558,8 @@ class SlaFn(torch.autograd.Function):
         wq2, wo2 = wqkv.detach().reshape(3 * hid, c), wout.detach().reshape(c, hid)
         wp = (wq2 * gamma.detach().reshape(1, c)).contiguous()
         qkv = conv_rows(xh, _linear_pack(wp, False), None, frames, f, h, w)
-        p_ctx = _sla_partials(frames, n, heads, x.device)
         base = qkv.data_ptr()
-        check(lib.vdmi_sla_train_reduce(base + 2 * hid, 3 * hid, base + 4 * hid, 3 * hid, p_ctx.data_ptr(), frames, n, heads, 0,
-                                        _stream()), "vdmi_sla_train_reduce")
+        p_ctx = _sla_reduce(base + 2 * hid, 3 * hid, base + 4 * hid, 3 * hid, None, frames, n, heads, 0, x.device)
         out = torch.empty(rows, hid, device=x.device, dtype=torch.bfloat16)
         qt = torch.empty_like(out)
         check(lib.vdmi_sla_train_rows_fwd(qkv.data_ptr(), p_ctx.data_ptr(), out.data_ptr(), qt.data_ptr(), frames, n, heads,
@@ -578,9 +582,7 @@ class SlaFn(torch.autograd.Function):
         wo2 = wout.detach().reshape(c, hid).contiguous()
         do = conv_rows(dyr, _linear_pack(wo2, True), None, frames, f, h, w)
         dwout = conv_wgrad(rows_transposed(out, frames, n), rows_transposed(dyr, frames, n), hid, c, frames, h, w, 1)
-        p_dctx = _sla_partials(frames, n, heads, dy.device)
-        check(lib.vdmi_sla_train_reduce(qt.data_ptr(), hid, do.data_ptr(), hid, p_dctx.data_ptr(), frames, n, heads, 1,
-                                        _stream()), "vdmi_sla_train_reduce")
+        p_dctx = _sla_reduce(qt.data_ptr(), hid, do.data_ptr(), hid, p_ctx, frames, n, heads, 1, dy.device)
         dqkv = torch.empty_like(qkv)
         check(lib.vdmi_sla_train_rows_bwd(qkv.data_ptr(), qt.data_ptr(), do.data_ptr(), p_ctx.data_ptr(), p_dctx.data_ptr(),
                                           dqkv.data_ptr(), frames, n, heads, scale, _stream()), "vdmi_sla_train_rows_bwd")
