@@ -121,9 +121,9 @@ def train_step(args, dev):
     import torch.nn.functional as F
     from video_diffusion_amd import Unet3D
     torch.manual_seed(0)
-    unet = Unet3D(dim=128, dim_mults=(1, 2, 4, 8), channels=3).to(dev)
+    unet = Unet3D(dim=args.train_dim, dim_mults=(1, 2, 4, 8), channels=args.train_channels).to(dev)
     B = args.train_batch
-    x = torch.randn(B, 3, 16, args.train_size, args.train_size, device=dev)
+    x = torch.randn(B, args.train_channels, args.train_frames, args.train_size, args.train_size, device=dev)
     noise = torch.randn_like(x)
     t = torch.randint(0, 1000, (B,), device=dev)
 
@@ -136,7 +136,7 @@ def train_step(args, dev):
         loss.backward()
         return loss
 
-    out = {"workload": f"training step: Unet3D(dim=128, channels=3) p_losses forward + backward on {tuple(x.shape)}, "
+    out = {"workload": f"training step: Unet3D(dim={args.train_dim}, channels={args.train_channels}) p_losses forward + backward on {tuple(x.shape)}, "
                        "random-init weights, no optimizer step", "ms_per_step": {}, "loss": {}, "peak_mem_gib": {}}
     runs = (("hip + bf16 autocast of the torch layers", "hip", True), ("hip", "hip", False),
             ("hip-resnet", "hip-resnet", False), ("hip-resnet + bf16 autocast of the torch layers", "hip-resnet", True),
@@ -172,6 +172,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train-batch", type=int, default=1)
     ap.add_argument("--train-size", type=int, default=128)
+    ap.add_argument("--train-dim", type=int, default=128)
+    ap.add_argument("--train-frames", type=int, default=16)
+    ap.add_argument("--train-channels", type=int, default=3)
     ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--train-profile-backend", default="hip")
     ap.add_argument("--train-profile", default="", help="fp32 | amp: add per-kernel times of one hip-resnet step")
