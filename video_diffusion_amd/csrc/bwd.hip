@@ -709,8 +709,10 @@ extern "C" int vdmi_rmsnorm_silu_bwd(const void* y, int ldy, const void* dh, int
     a.dgamma = dgamma; a.dbias = dbias; a.dscale = dscale; a.dshift = dshift;
     a.rows_per_batch = rows_per_batch; a.c = c; a.norm_scale = norm_scale;
     const int R = 256 / (c / 8);
-    // chunks of ~64 passes: long enough to amortise the per-channel atomics, short enough to fill the device
-    long long per = (long long)R * 64;
+    // 16 passes per workgroup: a pass is one load - reduce - reduce - store chain, and only other workgroups on the CU
+    // cover its latency (64 passes: 130 us per layer at 16 x 128 x 128, 16 passes: 65 us); the price is one atomic per
+    // channel and workgroup
+    long long per = (long long)R * 16;
     long long chunks = (rows_per_batch + per - 1) / per;
     if (chunks > 0x7fffffffLL) return VDMI_E_SHAPE;
     a.rows_per_chunk = per;
@@ -726,7 +728,7 @@ extern "C" int vdmi_colsum(const void* x, int ld, int64_t rows, int c, float* ou
     if (!aligned16(x)) return VDMI_E_ALIGN;
     const int R = 256 / (c / 8);
     if (R < 1) return VDMI_E_SHAPE;
-    const long long per = (long long)R * 64;
+    const long long per = (long long)R * 16;
     const long long chunks = (rows + per - 1) / per;
     if (chunks > 0x7fffffffLL) return VDMI_E_SHAPE;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
