@@ -405,9 +405,11 @@ int vdmi_ddpm_step_thres(const float* x, const float* eps, const float* z, const
 int vdmi_pack_taps_device(const float* w, int n, int npad, int cin0, int cin1, int ntaps, int bkc, int transposed,
                           void* out, vdmi_stream stream);
 
-/* rows bf16 [nf*hw][ld], channel window [c_off, c_off + c)  ->  out bf16 [c][hw][nfpad], nfpad = nf rounded up to a
- * multiple of 16, frames beyond nf zero: the operand layout of vdmi_conv_wgrad (the frame is the fast contraction
- * index, so a tap shift never breaks a 16-byte fragment).  out holds vdmi_rows_transpose_elems() elements. */
+/* rows bf16 [nf*hw][ld], channel window [c_off, c_off + c)  ->  out bf16 [ceil(nf/16)][ceil(c/32)][hw][32][16]
+ * (frame block, channel block, pixel, channel in block, frame in block), frames beyond nf and channels beyond c zero:
+ * the operand layout of vdmi_conv_wgrad (the frame is the fast contraction index, so a tap shift never breaks a
+ * 16-byte fragment, and the 32 channels x 16 frames a wave needs for one pixel are one contiguous KiB).  out holds
+ * vdmi_rows_transpose_elems() elements. */
 size_t vdmi_rows_transpose_elems(int c, int nf, int64_t hw);                              /* HOST */
 int vdmi_rows_transpose(const void* rows, int ld, int c_off, int c, int nf, int64_t hw, void* out, vdmi_stream stream);
 

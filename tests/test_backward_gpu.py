@@ -54,10 +54,12 @@ def test_rows_transpose():
     for nf, hw, c in [(10, 64, 64), (20, 35, 72), (16, 9, 8)]:
         rows = _bf(torch.randn(nf * hw, c, generator=g)).to(DEV)
         out = T.rows_transposed(rows, nf, hw)
-        nfpad = (nf + 15) // 16 * 16
-        ref = torch.zeros(c, hw, nfpad, dtype=torch.bfloat16, device=DEV)
-        ref[:, :, :nf] = rows.view(nf, hw, c).permute(2, 1, 0)
-        assert torch.equal(out.view(c, hw, nfpad), ref)
+        nfb, cb = (nf + 15) // 16, (c + 31) // 32
+        ref = torch.zeros(cb * 32, hw, nfb * 16, dtype=torch.bfloat16, device=DEV)
+        ref[:c, :, :nf] = rows.view(nf, hw, c).permute(2, 1, 0)
+        # [frame block][channel block][pixel][channel in block][frame in block]
+        ref = ref.view(cb, 32, hw, nfb, 16).permute(3, 0, 2, 1, 4).contiguous()
+        assert torch.equal(out.view(nfb, cb, hw, 32, 16), ref)
 
 
 @pytest.mark.parametrize("nf,h,w,cin,cout,ntaps", [(10, 8, 8, 64, 64, 9), (20, 12, 10, 72, 40, 9), (3, 16, 16, 128, 64, 9),

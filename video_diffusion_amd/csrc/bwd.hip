@@ -7,8 +7,9 @@
 //
 //   wgrad contracts over pixels: dW[co][ci][tap] = sum_p dy[p][co] * x[p + off(tap)][ci].  With channels-last rows
 //   the contraction index is the slow one, and an MFMA operand wants 8 consecutive contraction values per lane.  The
-//   rows are therefore transposed once into [channel][pixel][frame] (vdmi_rows_transpose): the FRAME is the fast
-//   contraction index.  A tap moves (y, x) and never the frame, so the fragment of a shifted pixel is again 16
+//   rows are therefore transposed once into [frame block][channel / 32][pixel][channel % 32][16 frames]
+//   (vdmi_rows_transpose): the FRAME is the fast contraction index, and the fragment a wave needs for one pixel - 32
+//   channels x 16 frames - is one contiguous KiB.  A tap moves (y, x) and never the frame, so the fragment of a shifted pixel is again 16
 //   aligned bytes - no unaligned reads, and one 32 x 32 accumulator per tap.  The 1x1 form streams its fragments
 //   straight from L1/L2; the 3x3 form stages rows through LDS (see wgrad3x3_lds_kernel).  Workgroups split the
 //   pixels of a (co, ci) tile, write partial tiles and a second kernel adds them (floating-point atomics to the
@@ -55,13 +56,21 @@ __global__ __launch_bounds__(256) void pack_taps_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// rows [nf*hw][ld] (channel window c_off .. c_off + c) -> T[c][hw][nfpad], frames beyond nf are zero
+// rows [nf*hw][ld] (channel window c_off .. c_off + c) -> T[frame block][channel block][pixel][32][16]; frames beyond nf and
+// channels beyond c (up to the end of the last block) are zero
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int TP = 8;   // pixels per tile
+
+// element (channel c, pixel p, frame f) of a transposed tensor with `cb` channel blocks of 32
+__device__ __forceinline__ long long t_off(int c, long long p, int fb, int cb, long long hw) {
+    return ((((long long)fb * cb + (c >> 5)) * hw + p) * 32 + (c & 31)) * 16;
+}
+
 __global__ __launch_bounds__(256) void rows_transpose_kernel(const __bf16* __restrict__ rows, int ld, int c_off, int c,
-                                                             int nf, int hw, int nfpad, __bf16* __restrict__ out) {
+                                                             int nf, int hw, __bf16* __restrict__ out) {
     __shared__ __bf16 tile[16][TP][72];
-    const int p0 = blockIdx.x * TP, c0 = blockIdx.y * 64, f0 = blockIdx.z * 16, tid = threadIdx.x;
+    const int p0 = blockIdx.x * TP, c0 = blockIdx.y * 64, fb = blockIdx.z, f0 = fb * 16, tid = threadIdx.x;
+    const int cb = (c + 31) / 32;
     // load: 16 frames x TP pixels x 8 pieces of 8 channels
     for (int i = tid; i < 16 * TP * 8; i += 256) {
         const int pc = i & 7, p = (i >> 3) % TP, f = i / (8 * TP);
@@ -72,14 +81,15 @@ __global__ __launch_bounds__(256) void rows_transpose_kernel(const __bf16* __res
         *reinterpret_cast<bf16x8*>(&tile[f][p][pc * 8]) = v;
     }
     __syncthreads();
-    // store: 64 channels x TP pixels x 2 pieces of 8 frames
+    // store: 2 channel blocks x TP pixels x 32 channels x 2 pieces of 8 frames; a (block, pixel) is one contiguous KiB
     for (int i = tid; i < 64 * TP * 2; i += 256) {
-        const int fh = i & 1, p = (i >> 1) % TP, ch = i / (2 * TP);
-        if (c0 + ch >= c || p0 + p >= hw) continue;
+        const int fh = i & 1, cl = (i >> 1) & 31, p = (i >> 6) % TP, cbl = i / (64 * TP);
+        const int ch = cbl * 32 + cl;
+        if (c0 + cbl * 32 >= cb * 32 || p0 + p >= hw) continue;      // channels up to the block's end are written (zeros)
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = tile[fh * 8 + j][p][ch];
-        *reinterpret_cast<bf16x8*>(out + ((long long)(c0 + ch) * hw + p0 + p) * nfpad + f0 + fh * 8) = v;
+        *reinterpret_cast<bf16x8*>(out + t_off(c0 + ch, p0 + p, fb, cb, hw) + fh * 8) = v;
     }
 }
 
@@ -97,64 +107,72 @@ struct WgradArgs {
     int dy[9], dx[9];
 };
 
-template <int NT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+// One tap.  A wave's only work per unit is two fragment loads and one MFMA, so what bounds it is how many loads it has
+// in flight: units are taken eight at a time, the next eight requested before the current eight multiply (one unit
+// ahead: 70 TFLOP/s, the latency of a load pair per MFMA).
+constexpr int W1_U = 8;
+__global__ __launch_bounds__(256) void wgrad1_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int co = (blockIdx.x * 2 + (wave & 1)) * 32 + l31;      // this lane's A row
     const int ci = (blockIdx.y * 2 + (wave >> 1)) * 32 + l31;     // this lane's B column
     const int hw = a.h * a.w;
     const bool co_ok = co < a.cout, ci_ok = ci < a.cin;
-    const __bf16* ap = a.dyT + (long long)(co_ok ? co : 0) * hw * a.nfpad + 8 * half;
-    const __bf16* bp = a.xT + (long long)(ci_ok ? ci : 0) * hw * a.nfpad + 8 * half;
-
-    f32x16 acc[NT];
+    const int cbo = (a.cout + 31) / 32, cbi = (a.cin + 31) / 32;
+    const __bf16* ap = a.dyT + t_off(co_ok ? co : 0, 0, 0, cbo, hw) + 8 * half;
+    const __bf16* bp = a.xT + t_off(ci_ok ? ci : 0, 0, 0, cbi, hw) + 8 * half;
+    const long long fbs_a = (long long)cbo * hw * 512, fbs_b = (long long)cbi * hw * 512;    // elements per frame block
+    const int oy = a.dy[0], ox = a.dx[0];
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long u_begin = (long long)blockIdx.z * a.per;
+    const long long u_end = u_begin + a.per < a.units ? u_begin + a.per : a.units;
+    // position of the next unit to be requested
+    long long un = u_begin;
+    int fb = (int)(un / hw), p = (int)(un - (long long)fb * hw);
+    int y = p / a.w, x = p - y * a.w;
+    auto load_batch = [&](bf16x8 (&A)[W1_U], bf16x8 (&B)[W1_U]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    long long u = (long long)blockIdx.z * a.per;
-    const long long u_end = u + a.per < a.units ? u + a.per : a.units;
-    if (u < u_end) {
-        int fb = (int)(u / hw), p = (int)(u - (long long)fb * hw);
-        int y = p / a.w, x = p - y * a.w;
-        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto load_set = [&](bf16x8& A, bf16x8 (&B)[NT], int fb_, int p_, int y_, int x_) {
-            A = co_ok ? *reinterpret_cast<const bf16x8*>(ap + (long long)p_ * a.nfpad + fb_ * 16) : zero8;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int yy = y_ + a.dy[t], xx = x_ + a.dx[t];
-                const bool ok = ci_ok && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
-                B[t] = ok ? *reinterpret_cast<const bf16x8*>(bp + (long long)(yy * a.w + xx) * a.nfpad + fb_ * 16) : zero8;
+        for (int j = 0; j < W1_U; ++j) {
+            bf16x8 va = zero8, vb = zero8;
+            if (un < u_end) {
+                if (co_ok) va = *reinterpret_cast<const bf16x8*>(ap + (long long)p * 512 + fb * fbs_a);
+                const int yy = y + oy, xx = x + ox;
+                if (ci_ok && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w)
+                    vb = *reinterpret_cast<const bf16x8*>(bp + (long long)(yy * a.w + xx) * 512 + fb * fbs_b);
             }
-        };
-        bf16x8 A, B[NT];
-        load_set(A, B, fb, p, y, x);
-        for (; u < u_end; ++u) {
-            // next unit's fragments are requested before this unit's products
-            int nx = x + 1, ny = y, np = p + 1, nfb = fb;
-            if (nx == a.w) { nx = 0; ++ny; }
-            if (np == hw) { np = 0; ny = 0; ++nfb; }
-            bf16x8 An = zero8, Bn[NT];
+            A[j] = va;
+            B[j] = vb;
+            ++un; ++p; ++x;
+            if (x == a.w) { x = 0; ++y; }
+            if (p == hw) { p = 0; y = 0; ++fb; }
+        }
+    };
+    bf16x8 A0[W1_U], B0[W1_U], A1[W1_U], B1[W1_U];
+    if (u_begin < u_end) {
+        load_batch(A0, B0);
+        for (long long u = u_begin; u < u_end; u += 2 * W1_U) {
+            load_batch(A1, B1);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) Bn[t] = zero8;
-            if (u + 1 < u_end) load_set(An, Bn, nfb, np, ny, nx);
+            for (int j = 0; j < W1_U; j += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[j], B0[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[j + 1], B0[j + 1], acc1, 0, 0, 0);
+            }
+            load_batch(A0, B0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[t], acc[t], 0, 0, 0);
-            A = An;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) B[t] = Bn[t];
-            x = nx; y = ny; p = np; fb = nfb;
+            for (int j = 0; j < W1_U; j += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[j], B1[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[j + 1], B1[j + 1], acc1, 0, 0, 0);
+            }
         }
     }
-    // partial tile of this workgroup: [tap][64 rows][64 columns]; register r of this lane is row
+    // partial tile of this workgroup: [64 rows][64 columns]; register r of this lane is row
     // (r&3) + 8*(r>>2) + 4*half of the wave's 32, column l31
-    float* part = a.part + ((size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * (NT * 4096);
+    float* part = a.part + ((size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 4096;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            part[(t * 64 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + (wave >> 1) * 32 + l31] = acc[t][r];
+    for (int r = 0; r < 16; ++r)
+        part[((wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + (wave >> 1) * 32 + l31] = acc0[r] + acc1[r];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -180,8 +198,10 @@ __global__ __launch_bounds__(256) void wgrad_gather_kernel(const WgradGatherArgs
     const bool co_ok = co < a.cout, n_ok = n < a.cin * ntaps;
     const int ci = n_ok ? n / ntaps : 0, t = n_ok ? n - ci * ntaps : 0;
     const int ody = t / a.kw - a.kh / 2, odx = t % a.kw - a.kw / 2;
-    const __bf16* ap = a.dyT + (long long)(co_ok ? co : 0) * hw * a.nfpad + 8 * half;
-    const __bf16* bp = a.xT + (long long)ci * hw * a.nfpad + 8 * half;
+    const int cbo = (a.cout + 31) / 32, cbi = (a.cin + 31) / 32;
+    const __bf16* ap = a.dyT + t_off(co_ok ? co : 0, 0, 0, cbo, hw) + 8 * half;
+    const __bf16* bp = a.xT + t_off(ci, 0, 0, cbi, hw) + 8 * half;
+    const long long fbs_a = (long long)cbo * hw * 512, fbs_b = (long long)cbi * hw * 512;
     f32x16 acc0, acc1;      // even / odd units: neighbouring MFMAs never share an accumulator
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
@@ -192,10 +212,10 @@ __global__ __launch_bounds__(256) void wgrad_gather_kernel(const WgradGatherArgs
         int fb = (int)(u / hw), p = (int)(u - (long long)fb * hw);
         int y = p / a.w, x = p - y * a.w;
         auto load_set = [&](bf16x8& A, bf16x8& B, int fb_, int p_, int y_, int x_) {
-            A = co_ok ? *reinterpret_cast<const bf16x8*>(ap + (long long)p_ * a.nfpad + fb_ * 16) : zero8;
+            A = co_ok ? *reinterpret_cast<const bf16x8*>(ap + (long long)p_ * 512 + fb_ * fbs_a) : zero8;
             const int yy = y_ + ody, xx = x_ + odx;
             const bool ok = n_ok && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
-            B = ok ? *reinterpret_cast<const bf16x8*>(bp + (long long)(yy * a.w + xx) * a.nfpad + fb_ * 16) : zero8;
+            B = ok ? *reinterpret_cast<const bf16x8*>(bp + (long long)(yy * a.w + xx) * 512 + fb_ * fbs_b) : zero8;
         };
         auto advance = [&]() {
             ++p; ++x;
@@ -278,6 +298,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_lds_kernel(const Wgrad3Args a) {
     const int x0 = strip * WG_XT;
     const int y0 = yseg * a.yseg_rows, y1 = min(y0 + a.yseg_rows, a.h);
     const long long hw = (long long)a.h * a.w;
+    const int cbo = (a.cout + 31) / 32, cbi = (a.cin + 31) / 32;
 
     // staging pieces: x row = 64 ci x (XT+2) px x 2 halves, dy row = 64 co x XT px x 2 halves (16 bytes each)
     constexpr int XP = 64 * (WG_XT + 2) * 2, DP = 64 * WG_XT * 2, XN = (XP + 255) / 256, DN = DP / 256;
@@ -287,11 +308,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_lds_kernel(const Wgrad3Args a) {
 #pragma unroll
         for (int k = 0; k < XN; ++k) {
             const int i = tid + k * 256;
-            const int hf = i & 1, px = (i >> 1) % (WG_XT + 2), ch = i / (2 * (WG_XT + 2));
+            const int hf = i & 1, ch = ((i >> 1) & 31) + 32 * (i / (64 * (WG_XT + 2))), px = (i >> 6) % (WG_XT + 2);
             const int gx = x0 - 1 + px, gc = ci0 + ch;
             bf16x8 v = zero8;
             if (i < XP && row >= 0 && row < a.h && gx >= 0 && gx < a.w && gc < a.cin)
-                v = *reinterpret_cast<const bf16x8*>(a.xT + ((long long)gc * hw + (long long)row * a.w + gx) * a.nfpad + fb * 16 + hf * 8);
+                v = *reinterpret_cast<const bf16x8*>(a.xT + t_off(gc, (long long)row * a.w + gx, fb, cbi, hw) + hf * 8);
             xv[k] = v;
         }
     };
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_lds_kernel(const Wgrad3Args a) {
 #pragma unroll
         for (int k = 0; k < XN; ++k) {
             const int i = tid + k * 256;
-            const int hf = i & 1, px = (i >> 1) % (WG_XT + 2), ch = i / (2 * (WG_XT + 2));
+            const int hf = i & 1, ch = ((i >> 1) & 31) + 32 * (i / (64 * (WG_XT + 2))), px = (i >> 6) % (WG_XT + 2);
             if (i < XP) *reinterpret_cast<bf16x8*>(dst + ch * WG_XPITCH + px * 32 + hf * 16) = xv[k];
         }
     };
@@ -308,11 +329,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_lds_kernel(const Wgrad3Args a) {
 #pragma unroll
         for (int k = 0; k < DN; ++k) {
             const int i = tid + k * 256;
-            const int hf = i & 1, px = (i >> 1) % WG_XT, ch = i / (2 * WG_XT);
+            const int hf = i & 1, ch = ((i >> 1) & 31) + 32 * (i / (64 * WG_XT)), px = (i >> 6) % WG_XT;
             const int gx = x0 + px, gc = co0 + ch;
             bf16x8 v = zero8;
             if (row < a.h && gx < a.w && gc < a.cout)
-                v = *reinterpret_cast<const bf16x8*>(a.dyT + ((long long)gc * hw + (long long)row * a.w + gx) * a.nfpad + fb * 16 + hf * 8);
+                v = *reinterpret_cast<const bf16x8*>(a.dyT + t_off(gc, (long long)row * a.w + gx, fb, cbo, hw) + hf * 8);
             dv[k] = v;
         }
     };
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_lds_kernel(const Wgrad3Args a) {
 #pragma unroll
         for (int k = 0; k < DN; ++k) {
             const int i = tid + k * 256;
-            const int hf = i & 1, px = (i >> 1) % WG_XT, ch = i / (2 * WG_XT);
+            const int hf = i & 1, ch = ((i >> 1) & 31) + 32 * (i / (64 * WG_XT)), px = (i >> 6) % WG_XT;
             *reinterpret_cast<bf16x8*>(dl + ch * WG_DPITCH + px * 32 + hf * 16) = dv[k];
         }
     };
@@ -550,7 +571,7 @@ extern "C" int vdmi_pack_taps_device(const float* w, int n, int npad, int cin0, 
 
 extern "C" size_t vdmi_rows_transpose_elems(int c, int nf, int64_t hw) {
     if (c <= 0 || nf <= 0 || hw <= 0) return 0;
-    return (size_t)c * (size_t)hw * (size_t)((nf + 15) / 16 * 16);
+    return (size_t)((c + 31) / 32 * 32) * (size_t)hw * (size_t)((nf + 15) / 16 * 16);
 }
 
 extern "C" int vdmi_rows_transpose(const void* rows, int ld, int c_off, int c, int nf, int64_t hw, void* out,
@@ -564,7 +585,7 @@ extern "C" int vdmi_rows_transpose(const void* rows, int ld, int c_off, int c, i
         return VDMI_E_SHAPE;
     hipLaunchKernelGGL(rows_transpose_kernel, dim3((unsigned)px, (unsigned)((c + 63) / 64), (unsigned)(nfpad / 16)),
                        dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(rows), ld, c_off, c, nf,
-                       (int)hw, nfpad, static_cast<__bf16*>(out));
+                       (int)hw, static_cast<__bf16*>(out));
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
@@ -649,7 +670,7 @@ extern "C" int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int c
         for (int t = 0; t < 9; ++t) { a.dy[t] = t < ntaps ? dy[t] : 0; a.dx[t] = t < ntaps ? dx[t] : 0; }
         a.units = p.units;
         a.per = p.per;
-        hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(wgrad1_kernel, grid, dim3(256), 0, s, a);
     }
     VDMI_LAUNCH_CHECK();
     const long long elems = (long long)p.tx * p.ty * ntaps * 4096;
