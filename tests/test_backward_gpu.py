@@ -346,6 +346,9 @@ def test_temporal_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w)
 
     out_ref, g_ref = run(False)
     out_hip, g_hip = run(True)
+    with torch.no_grad():       # the module called on its own, with the reference's keyword
+        assert torch.equal(res(x, pos_bias=bias0), out_hip)
+        assert torch.equal(res(x, pos_bias=bias0, focus_present_mask=torch.zeros(2, dtype=torch.bool, device=DEV)), out_hip)
     tag = f"tattn_layer.c{c}"
     assert record(tag + ".out", rel_err(out_hip, out_ref), 2e-2) < 2e-2
     assert set(g_hip) == set(g_ref)
@@ -432,6 +435,8 @@ def test_linear_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w):
 
     out_ref, g_ref = run(False)
     out_hip, g_hip = run(True)
+    with torch.no_grad():
+        assert torch.equal(res(x), out_hip)       # the module called on its own
     tag = f"sla_layer.c{c}"
     assert record(tag + ".out", rel_err(out_hip, out_ref), 2e-2) < 2e-2
     assert set(g_hip) == set(g_ref)

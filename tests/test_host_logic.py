@@ -66,3 +66,20 @@ def test_no_kernel_has_a_chain_of_adjacent_dependent_mfmas():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_chain_scan.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "chains of three or more: 0" in r.stdout
+
+
+def test_small_modules_on_their_own_match_the_oracle():
+    """RelativePositionBias(n, device) and SinusoidalPosEmb(t) called as the reference's modules are (vdp.py:306-312,
+    339-351): bit-equal to the oracle's restatement; sub-blocks that only run inside the fused pipeline still raise."""
+    import pytest
+    import torch
+    from oracle import vdm_oracle as O
+    from video_diffusion_amd.modules import Block, RelativePositionBias, SinusoidalPosEmb
+    rpb = RelativePositionBias(heads=8, num_buckets=32, max_distance=32)
+    with torch.no_grad():
+        for n in (1, 5, 10, 16):
+            assert torch.equal(rpb(n, "cpu"), O.relpos_bias(rpb.relative_attention_bias.weight, n, 32, 32))
+    t = torch.tensor([0., 3., 999.])
+    assert torch.equal(SinusoidalPosEmb(64)(t), O.sinusoidal_emb(t, 64))
+    with pytest.raises(NotImplementedError):
+        Block(64, 64)(torch.zeros(1, 64, 1, 8, 8))

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from functools import partial
 
+import math
+
 import torch
 from torch import nn
 
@@ -47,6 +49,17 @@ class RelativePositionBias(_HipOnly):
         self.max_distance = max_distance
         self.relative_attention_bias = nn.Embedding(num_buckets, heads)
 
+    def forward(self, n, device):
+        """The module on its own (reference vdp.py:306-312): bias [heads, n, n]; the integer buckets come from the
+        library's host routine (bit-identical to the reference's), the gather is differentiable."""
+        import numpy as np
+        from . import _lib
+        buckets = np.empty((n, n), dtype=np.int32)
+        _lib.check(_lib.lib().vdmi_relpos_buckets(n, self.num_buckets, self.max_distance, buckets.ctypes.data),
+                   "vdmi_relpos_buckets")
+        idx = torch.from_numpy(buckets.astype(np.int64)).to(device)
+        return self.relative_attention_bias(idx).permute(2, 0, 1)
+
 
 class RotaryEmbedding(_HipOnly):
     """Half-split rotary (the definition in the reference tree, video_diffusion_guidance.py:182-198).
@@ -72,11 +85,39 @@ class Residual(_HipOnly):
         super().__init__()
         self.fn = fn
 
+    def forward(self, x, *args, **kwargs):
+        """The two attention layers of a UNet level called on their own (reference vdp.py:331-337 around PreNorm):
+        Residual(PreNorm(SpatialLinearAttention)) and the temporal Residual(PreNorm(EinopsToAndFrom(Attention))) run
+        forward and backward on the HIP kernels (train_hip.py); x float (B, C, F, H, W) on the GPU.  The temporal layer
+        takes `pos_bias=` as in the reference; a focus_present_mask with any flag set is not served here."""
+        pre = self.fn
+        core = getattr(pre, "fn", None)
+        if isinstance(pre, PreNorm) and isinstance(core, SpatialLinearAttention):
+            from .train_hip import spatial_linear_attention
+            return spatial_linear_attention(self, x)
+        if (isinstance(pre, PreNorm) and isinstance(core, EinopsToAndFrom) and isinstance(core.fn, Attention)
+                and core.to_einops == 'b (h w) f c'):
+            mask = kwargs.get("focus_present_mask")
+            if mask is not None and bool(torch.as_tensor(mask).any()):
+                return super().forward(x, *args, **kwargs)
+            from . import autograd
+            from .train_hip import temporal_attention
+            rot = autograd._rot_tables(core.fn.rotary_emb, x.shape[2], x.device)
+            return temporal_attention(self, x, kwargs.get("pos_bias"), rot)
+        return super().forward(x, *args, **kwargs)
+
 
 class SinusoidalPosEmb(_HipOnly):
     def __init__(self, dim):
         super().__init__()
         self.dim = dim
+
+    def forward(self, x):
+        # reference vdp.py:339-351 (a handful of scalar operations per sample: host-side arithmetic, no kernel)
+        half = self.dim // 2
+        freq = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
+        ang = x[:, None] * freq[None, :]
+        return torch.cat((ang.sin(), ang.cos()), dim=-1)
 
 
 def Upsample(dim):
