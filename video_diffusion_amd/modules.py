@@ -1,7 +1,9 @@
 """Parameter containers with the reference's class names, constructor signatures and
 state-dict keys (``video_diffusion_pytorch/video_diffusion_pytorch.py:274-729`` of the
-reference).  They own ``nn.Parameter``s only; the arithmetic of the denoising path lives
-in the HIP library and is driven by :class:`video_diffusion_amd.engine.UnetEngine`.
+reference).  They own ``nn.Parameter``s; the arithmetic of the denoising path lives
+in the HIP library and is driven by :class:`video_diffusion_amd.engine.UnetEngine`.  A few of them can also be
+called on their own like the reference's modules (``ResnetBlock``, the ``Residual`` attention layers of a level,
+``RelativePositionBias``, ``SinusoidalPosEmb``); the rest raise when called outside ``Unet3D``.
 
 ``Unet3D.forward`` is the drop-in for the reference's ``Unet3D.forward`` on the sampling
 path (no autograd, no frame cross-attention features, focus-present mask all False).
