@@ -32,8 +32,10 @@ def _stream() -> int:
 
 
 def to_rows(x: torch.Tensor) -> torch.Tensor:
-    """(B, C, F, H, W) float -> channels-last bf16 rows [B*F*H*W][C]."""
-    return x.permute(0, 2, 3, 4, 1).reshape(-1, x.shape[1]).to(torch.bfloat16).contiguous()
+    """(B, C, F, H, W) float -> channels-last bf16 rows [B*F*H*W][C].  The cast comes first: a tensor that is already
+    channels-last in memory (what from_rows returns) then needs no second pass, and one in the standard layout is
+    transposed at two bytes per element instead of four."""
+    return x.to(torch.bfloat16).permute(0, 2, 3, 4, 1).reshape(-1, x.shape[1]).contiguous()
 
 
 def from_rows(r: torch.Tensor, b: int, f: int, h: int, w: int) -> torch.Tensor:
