@@ -606,9 +606,11 @@ int wgrad_plan(int cin, int cout, int nf, int h, int w, int ntaps, WgradPlan* p)
     const long long tiles = (long long)p->tx * p->ty;
     constexpr long long kTargetWgs = 768;       // ~3 per CU; every workgroup writes a 64 x 64 x taps partial tile
     if (ntaps == 9) {
+        // the LDS kernel holds 80 KB: two workgroups per CU, 512 on the device - one round of them, not one and a half
+        constexpr long long kTargetWgs3 = 512;
         p->strips = (w + WG_XT - 1) / WG_XT;
         const long long base = tiles * p->nfb * p->strips;
-        long long segs = (kTargetWgs + base - 1) / base;
+        long long segs = kTargetWgs3 / base;
         if (segs > (h + 3) / 4) segs = (h + 3) / 4;      // a segment re-reads two halo rows: at least 4 rows each
         if (segs < 1) segs = 1;
         p->yseg_rows = (int)((h + segs - 1) / segs);
