@@ -463,8 +463,9 @@ int vdmi_layernorm_rows_bwd(const void* x, const void* dxh, const void* add, voi
  * rows of to_qkv: qkv bf16 [b*f*hw][3*heads*32] (q | k | v, column = head*32 + feature; row = (b*f + frame)*hw + site).
  * q * scale, half-split rotary on q and k (rot_cos / rot_sin: float [f][16] or NULL), + bias (float [heads][f][f],
  * entry (query, key), or NULL), softmax over the keys, . v  ->  o bf16 [rows][heads*32], lse float [rows][heads]
- * (log-sum-exp of each row's scores, kept for the backward).  f <= 32, f*heads <= 256; the backward keeps four
- * f*heads x 32 float tiles and the bias-gradient table in LDS (VDMI_E_LDS beyond: f <= 24 at 8 heads).
+ * (log-sum-exp of each row's scores, kept for the backward).  f <= 256: a workgroup takes as many heads at a time as
+ * 256 threads and the LDS hold.  With hw = 1 the "frames" of a site are f consecutive rows: the mid-block spatial
+ * attention over the positions of a frame (vdp.py:708-710; b = frames, f = positions, no rotary, no bias).
  * Backward: from qkv, o, lse and dout (gradient of o) the gradient of the raw qkv rows (dqkv, same layout) and of the
  * bias (dbias float [heads][f][f], ACCUMULATED; may be NULL). */
 int vdmi_tattn_core_fwd(const void* qkv, void* o, float* lse, const float* bias, const float* rot_cos,

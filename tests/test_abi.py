@@ -182,16 +182,16 @@ def test_attention_training_entry_points_reject_bad_arguments():
     """Argument checks of the attention training entry points (every call returns before a launch)."""
     from video_diffusion_amd import _lib
     lib = _lib.lib()
-    E_ARG, E_SHAPE, E_ALIGN, E_LDS = -1, -2, -3, -5
+    E_ARG, E_SHAPE, E_ALIGN = -1, -2, -3
     assert lib.vdmi_layernorm_rows(None, 16, 10, 64, 1e-5, None) == E_ARG
     assert lib.vdmi_layernorm_rows(16, 16, 10, 96, 1e-5, None) == E_SHAPE                       # not a power of two
     assert lib.vdmi_layernorm_rows(16, 24, 10, 64, 1e-5, None) == E_ALIGN
     assert lib.vdmi_layernorm_rows_bwd(16, None, None, 16, 10, 64, 1e-5, None) == E_ARG
     assert lib.vdmi_tattn_core_fwd(None, 16, 16, None, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG
-    assert lib.vdmi_tattn_core_fwd(16, 16, 16, None, None, None, 1, 40, 64, 8, 0.17, None) == E_SHAPE    # f > 32
+    assert lib.vdmi_tattn_core_fwd(16, 16, 16, None, None, None, 1, 257, 64, 8, 0.17, None) == E_SHAPE   # f > 256
     assert lib.vdmi_tattn_core_fwd(16, 16, 16, None, 16, None, 1, 10, 64, 8, 0.17, None) == E_ARG        # cos without sin
     assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, 16, None, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG   # dbias, no bias
-    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, None, None, None, None, 1, 32, 64, 8, 0.17, None) == E_LDS
+    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, None, None, None, None, 1, 300, 64, 8, 0.17, None) == E_SHAPE  # f > 256
     assert lib.vdmi_sla_train_partial_bytes(16, 4096, 4) == 16 * 4 * 4 * (1024 + 64) * 4
     assert lib.vdmi_sla_train_combined_bytes(16, 4) == 16 * 4 * (1024 + 64) * 4
     assert lib.vdmi_sla_train_partial_bytes(16, 4096, 3) == 0                                   # 256 % heads

@@ -285,7 +285,8 @@ def _attn_core_ref(qkv, bias, cos, sin, b, f, hw, heads, scale):
 
 
 @pytest.mark.parametrize("b,f,hw,heads,rotary,with_bias", [(2, 10, 37, 8, True, True), (1, 16, 64, 8, True, True),
-                                                           (3, 5, 20, 4, False, False), (1, 24, 9, 8, True, True)])
+                                                           (3, 5, 20, 4, False, False), (1, 32, 9, 8, True, True),
+                                                           (3, 256, 1, 8, False, False), (2, 64, 1, 8, False, False)])
 def test_tattn_core_forward_backward_vs_torch(b, f, hw, heads, rotary, with_bias):
     from video_diffusion_amd import _lib
     lib = _lib.lib()
@@ -438,6 +439,40 @@ def test_linear_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w):
     with torch.no_grad():
         assert torch.equal(res(x), out_hip)       # the module called on its own
     tag = f"sla_layer.c{c}"
+    assert record(tag + ".out", rel_err(out_hip, out_ref), 2e-2) < 2e-2
+    assert set(g_hip) == set(g_ref)
+    for name in sorted(g_ref):
+        assert record(f"{tag}.grad.{name}", rel_err(g_hip[name], g_ref[name]), 3e-2) < 3e-2, name
+
+
+@pytest.mark.parametrize("c,f,h,w", [(256, 3, 16, 16), (512, 2, 8, 8)])
+def test_spatial_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w):
+    """The mid-block spatial attention (vdp.py:708-710) through the same Function against the torch ops of autograd.py."""
+    from video_diffusion_amd import autograd as A, train_hip as T
+    from video_diffusion_amd.modules import Attention, EinopsToAndFrom, PreNorm, Residual
+    torch.manual_seed(18)
+    res = Residual(PreNorm(c, EinopsToAndFrom('b c f h w', 'b f (h w) c', Attention(c, heads=8, dim_head=32)))).to(DEV)
+    with torch.no_grad():
+        res.fn.norm.gamma.copy_(1 + 0.2 * torch.randn_like(res.fn.norm.gamma))
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(2, c, f, h, w, generator=g).to(DEV)
+    dout = torch.randn(2, c, f, h, w, generator=g).to(DEV)
+
+    def run(hip):
+        xr = x.clone().requires_grad_(True)
+        for p in res.parameters():
+            p.grad = None
+        out = T.spatial_attention(res, xr) if hip else A._spatial(res, xr)
+        out.backward(dout)
+        grads = {n: p.grad.clone() for n, p in res.named_parameters() if p.grad is not None}
+        grads["x"] = xr.grad.clone()
+        return out.detach(), grads
+
+    out_ref, g_ref = run(False)
+    out_hip, g_hip = run(True)
+    with torch.no_grad():
+        assert torch.equal(res(x), out_hip)       # the module called on its own
+    tag = f"sattn_layer.c{c}"
     assert record(tag + ".out", rel_err(out_hip, out_ref), 2e-2) < 2e-2
     assert set(g_hip) == set(g_ref)
     for name in sorted(g_ref):

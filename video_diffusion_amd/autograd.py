@@ -119,6 +119,9 @@ def _temporal(res, x, pos_bias, focus=None):
 
 def _spatial(res, x):
     # mid_spatial_attn: 'b c f h w -> b f (h w) c', vdp.py:708-710
+    if _HIP_ATTN and x.is_cuda and x.shape[3] * x.shape[4] <= 256:
+        from .train_hip import spatial_attention      # forward and backward on the HIP kernels
+        return spatial_attention(res, x)
     b, c, f, h, w = x.shape
     y = _chan_layernorm(x, res.fn.norm).permute(0, 2, 3, 4, 1).reshape(b, f, h * w, c)
     o = _attention(res.fn.fn.fn, y)

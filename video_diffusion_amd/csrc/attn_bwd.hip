@@ -97,8 +97,9 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const LnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Attention core over frames.  qkv rows [b*f*hw][3*heads*32] (q | k | v, column = head*32 + feature); a site's f rows
-// are hw rows apart.  A workgroup takes `spw` sites at a time; thread = (site, head, frame).
+// Attention core over frames (or, with hw = 1, over the f consecutive rows of a group: the mid-block spatial attention over
+// the positions of a frame).  qkv rows [b*f*hw][3*heads*32] (q | k | v, column = head*32 + feature); a site's f rows are
+// hw rows apart.  A workgroup takes `spw` sites and `hpw` heads at a time; thread = (site, head, frame).
 // ------------------------------------------------------------------------------------------------------------------
 struct CoreArgs {
     const __bf16* qkv;
@@ -113,7 +114,8 @@ struct CoreArgs {
     const float* rot_sin;
     int b, f, hw, heads;
     int spw;                // sites per workgroup pass
-    long long groups;       // ceil(b*hw / spw)
+    int hpw, hgroups;       // heads per workgroup pass, heads / hpw (long token axes leave room for few heads at a time)
+    long long groups;       // ceil(b*hw / spw) * hgroups
     float scale;
 };
 
@@ -174,19 +176,20 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    const int F = a.f, H = a.heads, per_site = F * H, ld = 3 * H * 32, ldo = H * 32;
+    const int F = a.f, H = a.heads, HP = a.hpw, per_site = F * HP, ld = 3 * H * 32, ldo = H * 32;
     const int tile = a.spw * per_site * CORE_ROWF;                // floats per tensor
     float* Kl = reinterpret_cast<float*>(smem);
     float* Vl = Kl + tile;
     float* Ql = Vl + tile;                                        // bwd only
     float* Gl = Ql + tile;                                        // bwd only: gradient of o
     float* Sl = Gl + tile;                                        // bwd only: [slot][2] = (lse, D)
-    float* Bl = Sl + 2 * a.spw * per_site;                        // bwd only: dbias [heads][f][f]
+    float* Bl = Sl + 2 * a.spw * per_site;                        // bwd with a bias only: dbias [heads][f][f]
     const bool active = tid < a.spw * per_site;
-    const int s = tid / per_site, rem = tid - s * per_site, h = rem / F, i = rem - h * F;
-    const int slot = (s * F + i) * H + h;                         // this thread's row slot in the tiles
+    const int s = tid / per_site, rem = tid - s * per_site, hl = rem / F, i = rem - hl * F;
+    const int slot = (s * F + i) * HP + hl;                       // this thread's row slot in the tiles
     if constexpr (BWD) {
-        for (int k = tid; k < H * F * F; k += 256) Bl[k] = 0.f;
+        if (a.dbias)
+            for (int k = tid; k < H * F * F; k += 256) Bl[k] = 0.f;
     }
     float rc[16], rs[16];
 #pragma unroll
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
     }
     const long long nsites = (long long)a.b * a.hw;
     for (long long grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
-        const long long site = grp * a.spw + s;
+        const long long site = (grp / a.hgroups) * a.spw + s;
+        const int h = (int)(grp % a.hgroups) * HP + hl;           // this pass's heads
         const bool valid = active && site < nsites;
         const long long bb = valid ? site / a.hw : 0, sp = valid ? site - bb * a.hw : 0;
         const long long row = (bb * F + i) * a.hw + sp;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
 #pragma unroll
                 for (int d = 0; d < 32; ++d) o[d] = 0.f;
                 for (int j = 0; j < F; ++j) {
-                    const int sj = ((s * F + j) * H + h) * CORE_ROWF;
+                    const int sj = ((s * F + j) * HP + hl) * CORE_ROWF;
                     const float sc = lds_dot32(Kl + sj, q) + (bias_i ? bias_i[j] : 0.f);
                     const float mn = fmaxf(m, sc);
                     const float corr = __expf(m - mn), p = __expf(sc - mn);
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
 #pragma unroll
                 for (int d = 0; d < 32; ++d) dq[d] = 0.f;
                 for (int j = 0; j < F; ++j) {
-                    const int sj = ((s * F + j) * H + h) * CORE_ROWF;
+                    const int sj = ((s * F + j) * HP + hl) * CORE_ROWF;
                     const float sc = lds_dot32(Kl + sj, q) + (bias_i ? bias_i[j] : 0.f);
                     const float p = __expf(sc - lse);
                     const float ds = p * (lds_dot32(Vl + sj, g) - D);
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
 #pragma unroll
                 for (int d = 0; d < 32; ++d) dk[d] = dv[d] = 0.f;
                 for (int qi = 0; qi < F; ++qi) {
-                    const int slq = (s * F + qi) * H + h, sq = slq * CORE_ROWF;
+                    const int slq = (s * F + qi) * HP + hl, sq = slq * CORE_ROWF;
                     const float bq = a.bias ? a.bias[((long long)h * F + qi) * F + i] : 0.f;
                     const float sc = lds_dot32(Ql + sq, k) + bq;
                     const float p = __expf(sc - Sl[2 * slq]);
@@ -295,21 +299,32 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
     }
 }
 
-size_t core_lds_bytes(bool bwd, int f, int heads, int spw) {
-    const size_t tile = (size_t)spw * f * heads * CORE_ROWF * 4;
-    return bwd ? 4 * tile + (size_t)2 * spw * f * heads * 4 + (size_t)heads * f * f * 4 : 2 * tile;
+size_t core_lds_bytes(bool bwd, int f, int hpw, int spw, int bias_heads) {
+    const size_t tile = (size_t)spw * f * hpw * CORE_ROWF * 4;
+    return bwd ? 4 * tile + (size_t)2 * spw * f * hpw * 4 + (size_t)bias_heads * f * f * 4 : 2 * tile;
 }
 
 int core_launch(bool bwd, CoreArgs& a, hipStream_t stream) {
-    if (a.b <= 0 || a.f <= 0 || a.f > 32 || a.hw <= 0 || a.heads <= 0 || a.f * a.heads > 256) return VDMI_E_SHAPE;
+    if (a.b <= 0 || a.f <= 0 || a.f > 256 || a.hw <= 0 || a.heads <= 0) return VDMI_E_SHAPE;
     if ((a.rot_cos == nullptr) != (a.rot_sin == nullptr)) return VDMI_E_ARG;
-    int spw = 256 / (a.f * a.heads);
-    while (spw > 1 && core_lds_bytes(bwd, a.f, a.heads, spw) > 160 * 1024) --spw;
-    const size_t lds = core_lds_bytes(bwd, a.f, a.heads, spw);
-    if (lds > 160 * 1024) return VDMI_E_LDS;
+    // the most heads per pass (a divisor of heads) and sites per pass that 256 threads and the LDS hold
+    const int bias_heads = (bwd && a.dbias) ? a.heads : 0;
+    int hpw = 0, spw = 0;
+    size_t lds = 0;
+    for (int hp = a.heads; hp >= 1 && !hpw; --hp) {
+        if (a.heads % hp || a.f * hp > 256) continue;
+        for (int sp = 256 / (a.f * hp); sp >= 1; --sp)
+            if (core_lds_bytes(bwd, a.f, hp, sp, bias_heads) <= 160 * 1024) {
+                hpw = hp; spw = sp; lds = core_lds_bytes(bwd, a.f, hp, sp, bias_heads);
+                break;
+            }
+    }
+    if (!hpw) return VDMI_E_LDS;
     a.spw = spw;
+    a.hpw = hpw;
+    a.hgroups = a.heads / hpw;
     const long long nsites = (long long)a.b * a.hw;
-    a.groups = (nsites + spw - 1) / spw;
+    a.groups = ((nsites + spw - 1) / spw) * a.hgroups;
     if ((long long)a.b * a.f * a.hw > 0x7fffffffLL) return VDMI_E_SHAPE;
     // persistent workgroups (the backward flushes its bias-gradient table once per workgroup)
     const long long grid = a.groups < 1024 ? a.groups : 1024;

@@ -106,6 +106,10 @@ class Residual(_HipOnly):
             from .train_hip import temporal_attention
             rot = autograd._rot_tables(core.fn.rotary_emb, x.shape[2], x.device)
             return temporal_attention(self, x, kwargs.get("pos_bias"), rot)
+        if (isinstance(pre, PreNorm) and isinstance(core, EinopsToAndFrom) and isinstance(core.fn, Attention)
+                and core.to_einops == 'b f (h w) c' and core.fn.rotary_emb is None):
+            from .train_hip import spatial_attention          # the mid-block attention over the positions of a frame
+            return spatial_attention(self, x)
         return super().forward(x, *args, **kwargs)
 
 

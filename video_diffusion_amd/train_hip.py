@@ -317,7 +317,7 @@ class TemporalAttnFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, gamma, wqkv, wout, bias, cos, sin, heads, scale, eps):
+    def forward(ctx, x, gamma, wqkv, wout, bias, cos, sin, heads, scale, eps, spatial=False):
         if not x.is_cuda:
             raise _lib.VdmiError("the HIP training backend needs CUDA (HIP) tensors; there is no CPU path")
         lib = _lib.lib()
@@ -333,18 +333,20 @@ class TemporalAttnFn(torch.autograd.Function):
         lse = torch.empty(rows, heads, device=x.device, dtype=torch.float32)
         bias_c = None if bias is None else bias.detach().float().contiguous()
         ptr = lambda t: None if t is None else t.data_ptr()
-        check(lib.vdmi_tattn_core_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ptr(bias_c), ptr(cos), ptr(sin), b, f, hw,
+        # groups of the core: the f frames of a site (rows hw apart), or - spatial - the hw positions of a frame (consecutive rows)
+        core = (b * f, hw, 1) if spatial else (b, f, hw)
+        check(lib.vdmi_tattn_core_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ptr(bias_c), ptr(cos), ptr(sin), *core,
                                       heads, scale, _stream()), "vdmi_tattn_core_fwd")
         y = conv_rows(o, _linear_pack(wout.detach().contiguous(), False), None, b * f, f, h, w, residual=xr)
         ctx.save_for_backward(xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin)
-        ctx.meta = (b, c, f, h, w, heads, scale, eps)
+        ctx.meta = (b, c, f, h, w, heads, scale, eps, core)
         return from_rows(y, b, f, h, w)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin = ctx.saved_tensors
-        b, c, f, h, w, heads, scale, eps = ctx.meta
+        b, c, f, h, w, heads, scale, eps, core = ctx.meta
         lib = _lib.lib()
         hw, rows, hid, frames = h * w, b * f * h * w, heads * 32, b * f
         ptr = lambda t: None if t is None else t.data_ptr()
@@ -357,7 +359,7 @@ class TemporalAttnFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias_c) if bias_c is not None else None
         check(lib.vdmi_tattn_core_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                      ptr(dbias), ptr(bias_c), ptr(cos), ptr(sin), b, f, hw, heads, scale, _stream()),
+                                      ptr(dbias), ptr(bias_c), ptr(cos), ptr(sin), *core, heads, scale, _stream()),
               "vdmi_tattn_core_bwd")
         # to_qkv (with the folded gamma), LayerNorm, residual
         dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
@@ -368,7 +370,17 @@ class TemporalAttnFn(torch.autograd.Function):
         dx = torch.empty_like(xr)
         check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
                                           _stream()), "vdmi_layernorm_rows_bwd")
-        return from_rows(dx, b, f, h, w), dgamma, dwqkv, dwout, dbias, None, None, None, None, None
+        return from_rows(dx, b, f, h, w), dgamma, dwqkv, dwout, dbias, None, None, None, None, None, None
+
+
+def spatial_attention(res, x: torch.Tensor) -> torch.Tensor:
+    """autograd.py's `_spatial` (the mid-block attention over the positions of each frame, vdp.py:708-710: no rotary, no
+    bias) on the HIP kernels; up to 256 positions per frame."""
+    att = res.fn.fn.fn
+    if att.dim_head != 32 or x.shape[3] * x.shape[4] > 256:
+        raise _lib.VdmiError("the HIP spatial attention takes heads of 32 features and frames of at most 256 positions")
+    return TemporalAttnFn.apply(x, res.fn.norm.gamma, att.to_qkv.weight, att.to_out.weight, None, None, None, att.heads,
+                                float(att.scale), float(res.fn.norm.eps), True)
 
 
 def temporal_attention(res, x: torch.Tensor, pos_bias, rot_tables) -> torch.Tensor:
