@@ -300,7 +300,7 @@ class Trainer(object):
         if hasattr(self.model.denoise_fn, "train_backend"):
             # "torch-autograd": every layer differentiates through torch ops; "hip-resnet": the ResnetBlocks (and the weight
             # gradients of init_conv / final_conv) run forward and backward on the HIP kernels (train_hip.py); "hip": the
-            # temporal and linear attention layers and the Downsample / Upsample convolutions too
+            # temporal, linear and spatial attention layers and the Downsample / Upsample convolutions too
             self.model.denoise_fn.train_backend = self.train_backend
         loss_mod = _LossModule(self.model, self.null_frame_cond_prob)
         if self.distributed:
