@@ -477,3 +477,22 @@ def test_spatial_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w):
     assert set(g_hip) == set(g_ref)
     for name in sorted(g_ref):
         assert record(f"{tag}.grad.{name}", rel_err(g_hip[name], g_ref[name]), 3e-2) < 3e-2, name
+
+
+def test_input_gradient_alone_skips_the_weight_gradients():
+    """torch.autograd.grad with respect to the input only (reconstruction guidance at sampling time, reference
+    version1diffusion.py:707-747, or frozen weights): the same input gradient as a full backward, no parameter gradients."""
+    from tests.helpers import inp, make_unet
+    m = make_unet(salt=2, dim=64, dim_mults=(1, 2), channels=3).to(DEV)
+    m.train_backend = "hip"
+    x = inp("bwd.x", (1, 3, 4, 16, 16)).to(DEV)
+    t = torch.tensor([17], device=DEV)
+    xa = x.clone().requires_grad_(True)
+    m(xa, t).square().mean().backward()
+    xb = x.clone().requires_grad_(True)
+    for p in m.parameters():
+        p.grad = None
+    (gx,) = torch.autograd.grad(m(xb, t).square().mean(), xb)
+    m.train_backend = None
+    assert all(p.grad is None for p in m.parameters())
+    assert rel_err(gx, xa.grad) < 1e-6

@@ -201,21 +201,25 @@ class ResnetBlockFn(torch.autograd.Function):
         frames, hw = b * f, h * w
         do = to_rows(dout)
         # block2: SiLU / RMSNorm, then the conv
+        # weight gradients only where asked for (a gradient with respect to the input alone - guidance at sampling time,
+        # frozen weights - needs neither the transposes nor the contraction over pixels)
+        need = ctx.needs_input_grad
         dy2, dg2, db2, _, _ = rmsnorm_silu_bwd_rows(y2, do, g2v, None, None, b, f * hw)
-        dy2_t = rows_transposed(dy2, frames, hw)
-        dw2 = conv_wgrad(rows_transposed(h1, frames, hw), dy2_t, cout, cout, frames, h, w, 9)
+        dw2 = None
+        if need[6]:
+            dw2 = conv_wgrad(rows_transposed(h1, frames, hw), rows_transposed(dy2, frames, hw), cout, cout, frames, h, w, 9)
         dh1 = conv_rows(dy2, DevPack(w2, True), None, frames, f, h, w)
         # block1
         dy1, dg1, db1, dscale, dshift = rmsnorm_silu_bwd_rows(y1, dh1, g1v, scale_c, shift_c, b, f * hw)
-        x_t = rows_transposed(xr, frames, hw)
-        dw1 = conv_wgrad(x_t, rows_transposed(dy1, frames, hw), cin, cout, frames, h, w, 9)
+        x_t = rows_transposed(xr, frames, hw) if (need[3] or (wres is not None and need[9])) else None
+        dw1 = conv_wgrad(x_t, rows_transposed(dy1, frames, hw), cin, cout, frames, h, w, 9) if need[3] else None
         # residual branch, then the input gradient: dgrad of conv1 + (res_conv's dgrad | the identity)
         if wres is None:
             dwres = dbres = None
             dx_res = do
         else:
-            dwres = conv_wgrad(x_t, rows_transposed(do, frames, hw), cin, cout, frames, h, w, 1)
-            dbres = colsum_rows(do)
+            dwres = conv_wgrad(x_t, rows_transposed(do, frames, hw), cin, cout, frames, h, w, 1) if need[9] else None
+            dbres = colsum_rows(do) if need[10] else None
             dx_res = conv_rows(do, DevPack(wres, True), None, frames, f, h, w)
         dx = conv_rows(dy1, DevPack(w1, True), None, frames, f, h, w, residual=dx_res)
         return (from_rows(dx, b, f, h, w), dscale, dshift, dw1, db1, dg1.view(cout, 1, 1, 1), dw2, db2,
@@ -352,21 +356,26 @@ class TemporalAttnFn(torch.autograd.Function):
         ptr = lambda t: None if t is None else t.data_ptr()
         dyr = to_rows(dy)
         # to_out: gradient of its input and of its weight
+        need = ctx.needs_input_grad
         do = conv_rows(dyr, _linear_pack(wout.detach().contiguous(), True), None, frames, f, h, w)
-        dyr_t = rows_transposed(dyr, frames, hw)
-        dwout = conv_wgrad(rows_transposed(o, frames, hw), dyr_t, hid, c, frames, h, w, 1).reshape(c, hid)
+        dwout = None
+        if need[3]:
+            dwout = conv_wgrad(rows_transposed(o, frames, hw), rows_transposed(dyr, frames, hw), hid, c, frames, h, w,
+                               1).reshape(c, hid)
         # attention core
         dqkv = torch.empty_like(qkv)
-        dbias = torch.zeros_like(bias_c) if bias_c is not None else None
+        dbias = torch.zeros_like(bias_c) if (bias_c is not None and need[4]) else None
         check(lib.vdmi_tattn_core_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
                                       ptr(dbias), ptr(bias_c), ptr(cos), ptr(sin), *core, heads, scale, _stream()),
               "vdmi_tattn_core_bwd")
         # to_qkv (with the folded gamma), LayerNorm, residual
         dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
-        dwp = conv_wgrad(rows_transposed(xh, frames, hw), rows_transposed(dqkv, frames, hw), c, 3 * hid, frames, h, w,
-                         1).reshape(3 * hid, c)
-        dwqkv = dwp * gamma.detach().reshape(1, c)
-        dgamma = (dwp * wqkv.detach()).sum(0).reshape(gamma.shape)
+        dwqkv = dgamma = None
+        if need[1] or need[2]:
+            dwp = conv_wgrad(rows_transposed(xh, frames, hw), rows_transposed(dqkv, frames, hw), c, 3 * hid, frames, h, w,
+                             1).reshape(3 * hid, c)
+            dwqkv = dwp * gamma.detach().reshape(1, c)
+            dgamma = (dwp * wqkv.detach()).sum(0).reshape(gamma.shape)
         dx = torch.empty_like(xr)
         check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
                                           _stream()), "vdmi_layernorm_rows_bwd")
@@ -503,8 +512,8 @@ class DownsampleFn(torch.autograd.Function):
         dyr = to_rows(dy)
         # the input gradient of a strided convolution is the transposed convolution with the same weight tensor
         dx = up_conv_rows(dyr, weight, None, b * f, f, h // 2, w // 2)
-        dw = strided_wgrad(xr, dyr, b * f, h, w)
-        return from_rows(dx, b, f, h, w), dw, colsum_rows(dyr)
+        dw = strided_wgrad(xr, dyr, b * f, h, w) if ctx.needs_input_grad[1] else None
+        return from_rows(dx, b, f, h, w), dw, colsum_rows(dyr) if ctx.needs_input_grad[2] else None
 
 
 class UpsampleFn(torch.autograd.Function):
@@ -526,8 +535,8 @@ class UpsampleFn(torch.autograd.Function):
         dyr = to_rows(dy)
         # ... and the input gradient of the transposed convolution is the strided convolution with the same weight tensor
         dx = down_conv_rows(dyr, weight, None, b * f, f, 2 * h, 2 * w)
-        dw = strided_wgrad(dyr, xr, b * f, 2 * h, 2 * w)
-        return from_rows(dx, b, f, h, w), dw, colsum_rows(dyr)
+        dw = strided_wgrad(dyr, xr, b * f, 2 * h, 2 * w) if ctx.needs_input_grad[1] else None
+        return from_rows(dx, b, f, h, w), dw, colsum_rows(dyr) if ctx.needs_input_grad[2] else None
 
 
 def resample(mod, x: torch.Tensor) -> torch.Tensor:
@@ -594,21 +603,27 @@ class SlaFn(torch.autograd.Function):
         rows = frames * n
         dyr = to_rows(dy)
         wo2 = wout.detach().reshape(c, hid).contiguous()
+        need = ctx.needs_input_grad
         do = conv_rows(dyr, _linear_pack(wo2, True), None, frames, f, h, w)
-        dwout = conv_wgrad(rows_transposed(out, frames, n), rows_transposed(dyr, frames, n), hid, c, frames, h, w, 1)
+        dwout = None
+        if need[3]:
+            dwout = conv_wgrad(rows_transposed(out, frames, n), rows_transposed(dyr, frames, n), hid, c, frames, h, w,
+                               1).reshape(wout.shape)
         p_dctx = _sla_reduce(qt.data_ptr(), hid, do.data_ptr(), hid, p_ctx, frames, n, heads, 1, dy.device)
         dqkv = torch.empty_like(qkv)
         check(lib.vdmi_sla_train_rows_bwd(qkv.data_ptr(), qt.data_ptr(), do.data_ptr(), p_ctx.data_ptr(), p_dctx.data_ptr(),
                                           dqkv.data_ptr(), frames, n, heads, scale, _stream()), "vdmi_sla_train_rows_bwd")
         dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
-        dwp = conv_wgrad(rows_transposed(xh, frames, n), rows_transposed(dqkv, frames, n), c, 3 * hid, frames, h, w,
-                         1).reshape(3 * hid, c)
-        dwqkv = (dwp * gamma.detach().reshape(1, c)).reshape(wqkv.shape)
-        dgamma = (dwp * wqkv.detach().reshape(3 * hid, c)).sum(0).reshape(gamma.shape)
+        dwqkv = dgamma = None
+        if need[1] or need[2]:
+            dwp = conv_wgrad(rows_transposed(xh, frames, n), rows_transposed(dqkv, frames, n), c, 3 * hid, frames, h, w,
+                             1).reshape(3 * hid, c)
+            dwqkv = (dwp * gamma.detach().reshape(1, c)).reshape(wqkv.shape)
+            dgamma = (dwp * wqkv.detach().reshape(3 * hid, c)).sum(0).reshape(gamma.shape)
         dx = torch.empty_like(xr)
         check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
                                           _stream()), "vdmi_layernorm_rows_bwd")
-        return from_rows(dx, b, f, h, w), dgamma, dwqkv, dwout.reshape(wout.shape), colsum_rows(dyr), None, None, None
+        return (from_rows(dx, b, f, h, w), dgamma, dwqkv, dwout, colsum_rows(dyr) if need[4] else None, None, None, None)
 
 
 def spatial_linear_attention(res, x: torch.Tensor) -> torch.Tensor:
