@@ -241,3 +241,32 @@ def test_trainer_hip_resnet_backend_follows_torch_backend(tmp_path):
     amp_losses, _ = run("hip", str(tmp_path / "r_amp"), amp=True)
     for i, (a, b) in enumerate(zip(amp_losses, ref)):
         assert record(f"trainer_hip_amp.loss_step{i}", abs(a - b) / abs(b), 5e-2) < 5e-2
+
+
+@pytest.mark.gpu
+def test_reconstruction_guidance_gradient_on_hip_kernels_matches_torch_ops():
+    """temporal_consistency_guidance (version1diffusion.py:707-747) on a denoiser whose shapes the training kernels take:
+    the gradient through the HIP Blocks / temporal attention / resampling convolutions against the all-torch gradient."""
+    from video_diffusion_amd import VAE, train_hip, version1 as V1
+    from tests.helpers import record
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    unet = V1.Unet3D(dim=64, dim_mults=(1, 2), channels=4)
+    vae = VAE(channels=3, latent_dim=4, base_dim=64)
+    gd = V1.GaussianDiffusion(unet.eval(), vae.eval(), image_size=32, num_frames=3, channels=3, timesteps=250).to(dev)
+    assert train_hip.supports(gd.denoise_fn)
+    small = V1.Unet3D(dim=32, dim_mults=(1, 2), channels=4)
+    assert not train_hip.supports(small)                    # 32-channel blocks: the guidance falls back to torch ops
+    z = torch.randn(2, 4, 3, 4, 4, device=dev)
+    t = torch.tensor([40, 200], device=dev)
+    prev = torch.rand(2, 3, 2, 32, 32, device=dev)
+    fn = V1.temporal_consistency_guidance(gd, prev, 2, w_r=3.0)
+    g_hip = fn(z, t)
+    orig = train_hip.supports
+    train_hip.supports = lambda m: False                    # the all-torch path
+    try:
+        g_ref = fn(z, t)
+    finally:
+        train_hip.supports = orig
+    assert gd.denoise_fn.train_backend is None
+    assert record("v1_guidance.hip_vs_torch", rel_err(g_hip, g_ref), 5e-2) < 5e-2

@@ -46,7 +46,7 @@ _HIP_RESNET = False     # set by unet_forward for the duration of one forward (t
 
 def _resnet(rb, x, temb):
     # vdp.py:429-452; the (3,1,1) temporal conv of version1diffusion.py:308,322 when the block has one
-    if _HIP_RESNET and getattr(rb, "temporal_conv", None) is None:
+    if _HIP_RESNET and x.is_cuda:
         from .train_hip import resnet_block     # forward and backward on the HIP kernels
         return resnet_block(rb, x, temb)
     ss = None

@@ -176,8 +176,6 @@ class ResnetBlock(_HipOnly):
         (train_hip.py).  x float (B, dim, F, H, W) on the GPU; channel widths powers of two from 64 to 2048."""
         if exists(self.mlp):
             assert exists(time_emb), 'time emb must be passed in'
-        if getattr(self, "temporal_conv", None) is not None:
-            return super().forward(x, time_emb)      # the variant's block runs only inside its Unet3D
         from .train_hip import resnet_block
         return resnet_block(self, x, time_emb if exists(self.mlp) else None)
 

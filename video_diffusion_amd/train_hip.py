@@ -167,7 +167,8 @@ class ResnetBlockFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, scale, shift, w1, b1, g1, w2, b2, g2, wres, bres):
+    def forward(ctx, x, scale, shift, w1, b1, g1, w2, b2, g2, wres, bres, with_res=True):
+        # with_res = False: block2(block1(x)) alone, for callers that put a layer between the blocks and the residual
         if not x.is_cuda:
             raise _lib.VdmiError("the hip-resnet training backend needs CUDA (HIP) tensors; there is no CPU path")
         b, cin, f, h, w = x.shape
@@ -184,13 +185,17 @@ class ResnetBlockFn(torch.autograd.Function):
         y1 = conv_rows(xr, DevPack(w1, False), b1.detach().float().contiguous(), frames, f, h, w)
         h1 = rmsnorm_silu_rows(y1, gain1, shift_c, bstride, f * hw)
         y2 = conv_rows(h1, DevPack(w2, False), b2.detach().float().contiguous(), frames, f, h, w)
-        if wres is None:
+        if not with_res:
+            wres = None
+            out = rmsnorm_silu_rows(y2, g2v, None, 0, f * hw)
+        elif wres is None:
             out = rmsnorm_silu_rows(y2, g2v, None, 0, f * hw, residual=xr)
         else:
             h2 = rmsnorm_silu_rows(y2, g2v, None, 0, f * hw)
             out = conv_rows(xr, DevPack(wres, False), bres.detach().float().contiguous(), frames, f, h, w, residual=h2)
         ctx.save_for_backward(xr, y1, h1, y2, g1v, g2v, scale_c, shift_c, w1, w2, wres)
         ctx.dims = (b, cin, cout, f, h, w)
+        ctx.with_res = with_res
         return from_rows(out, b, f, h, w)
 
     @staticmethod
@@ -214,7 +219,9 @@ class ResnetBlockFn(torch.autograd.Function):
         x_t = rows_transposed(xr, frames, hw) if (need[3] or (wres is not None and need[9])) else None
         dw1 = conv_wgrad(x_t, rows_transposed(dy1, frames, hw), cin, cout, frames, h, w, 9) if need[3] else None
         # residual branch, then the input gradient: dgrad of conv1 + (res_conv's dgrad | the identity)
-        if wres is None:
+        if not ctx.with_res:
+            dwres = dbres = dx_res = None
+        elif wres is None:
             dwres = dbres = None
             dx_res = do
         else:
@@ -223,7 +230,7 @@ class ResnetBlockFn(torch.autograd.Function):
             dx_res = conv_rows(do, DevPack(wres, True), None, frames, f, h, w)
         dx = conv_rows(dy1, DevPack(w1, True), None, frames, f, h, w, residual=dx_res)
         return (from_rows(dx, b, f, h, w), dscale, dshift, dw1, db1, dg1.view(cout, 1, 1, 1), dw2, db2,
-                dg2.view(cout, 1, 1, 1), dwres, dbres)
+                dg2.view(cout, 1, 1, 1), dwres, dbres, None)
 
 
 class InitConvFn(torch.autograd.Function):
@@ -295,15 +302,41 @@ def pointwise_conv(conv: torch.nn.Conv3d, x: torch.Tensor) -> torch.Tensor:
 
 
 def resnet_block(rb, x: torch.Tensor, temb) -> torch.Tensor:
-    """autograd.py's `_resnet` on the HIP kernels (blocks without the variant's temporal convolution)."""
+    """autograd.py's `_resnet` on the HIP kernels.  The variant's block (version1diffusion.py:308, 320-323: a (3,1,1)
+    convolution over frames between block2 and the residual) runs its two Blocks here and the rest as torch ops."""
     scale = shift = None
     if rb.mlp is not None:
         e = rb.mlp[1](F.silu(temb))
         scale, shift = e.chunk(2, dim=1)
     rc = rb.res_conv
     wres, bres = (rc.weight, rc.bias) if isinstance(rc, torch.nn.Conv3d) else (None, None)
-    return ResnetBlockFn.apply(x, scale, shift, rb.block1.proj.weight, rb.block1.proj.bias, rb.block1.norm.gamma,
-                               rb.block2.proj.weight, rb.block2.proj.bias, rb.block2.norm.gamma, wres, bres)
+    args = (x, scale, shift, rb.block1.proj.weight, rb.block1.proj.bias, rb.block1.norm.gamma,
+            rb.block2.proj.weight, rb.block2.proj.bias, rb.block2.norm.gamma)
+    tconv = getattr(rb, "temporal_conv", None)
+    if tconv is not None:
+        return tconv(ResnetBlockFn.apply(*args, None, None, False)) + rc(x)
+    return ResnetBlockFn.apply(*args, wres, bres)
+
+
+def supports(unet) -> bool:
+    """True when every ResnetBlock, attention layer and resampling convolution of `unet` has a shape the training kernels
+    take (channel widths powers of two from 64 to 2048, heads of 32 features): what `train_backend = "hip"` needs."""
+    ok = lambda c: 64 <= c <= 2048 and (c & (c - 1)) == 0
+    for mod in unet.modules():
+        name = type(mod).__name__
+        if name == "ResnetBlock":
+            if not (ok(mod.block1.proj.out_channels) and mod.block1.proj.in_channels % 8 == 0):
+                return False
+        elif name in ("Attention", "SpatialLinearAttention", "SpatioTemporalAttention"):
+            if getattr(mod, "dim_head", 32) != 32:
+                return False
+        elif name == "PreNorm":
+            if not ok(mod.norm.gamma.numel()):
+                return False
+        elif isinstance(mod, (torch.nn.ConvTranspose3d, torch.nn.Conv3d)) and mod.kernel_size == (1, 4, 4):
+            if mod.in_channels % 64:
+                return False
+    return True
 
 
 # ---------------------------------------------------------------------------------------------------------------------

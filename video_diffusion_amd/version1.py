@@ -155,8 +155,10 @@ def temporal_consistency_injection(model, prev_latents, overlap_frames, save_gif
 
 def temporal_consistency_guidance(model, prev_frames, overlap_frames, w_r=1.0):
     """version1diffusion.py:707-747: -w_r * alphas_cumprod_t * d/dz_t mse(decode(x0_hat(z_t))[first frames], prev_frames).
-    The derivative runs through the denoiser and the VAE decoder as PyTorch autograd ops (autograd.py and the
-    VAE's torch layers: the HIP kernels are forward-only); the step that follows runs on the HIP kernels."""
+    The derivative runs through the denoiser and the VAE decoder.  On the GPU, when the denoiser's shapes allow it
+    (train_hip.supports), its Blocks, temporal attention layers and resampling convolutions run forward and backward on the
+    HIP kernels (train_backend "hip": only the input gradient is asked for, so no weight gradient is computed); the
+    remaining layers and the VAE decoder are PyTorch autograd ops.  The step that follows runs on the HIP kernels."""
     for param in model.vae.decoder.parameters():
         param.requires_grad = False
 
@@ -168,7 +170,8 @@ def temporal_consistency_guidance(model, prev_frames, overlap_frames, w_r=1.0):
         backend = getattr(fn, "train_backend", None)
         with torch.enable_grad():
             if hasattr(fn, "train_backend"):
-                fn.train_backend = "torch-autograd"
+                from . import train_hip
+                fn.train_backend = "hip" if (z.is_cuda and train_hip.supports(fn)) else "torch-autograd"
             try:
                 x_recon = model.predict_start_from_noise(z, t, fn(z, t))
                 overlap = x_recon[:, :, :overlap_frames] if x_recon.dim() == 5 else x_recon
