@@ -322,6 +322,13 @@ def supports(unet) -> bool:
     """True when every ResnetBlock, attention layer and resampling convolution of `unet` has a shape the training kernels
     take (channel widths powers of two from 64 to 2048, heads of 32 features): what `train_backend = "hip"` needs."""
     ok = lambda c: 64 <= c <= 2048 and (c & (c - 1)) == 0
+    try:
+        return _supports(unet, ok)
+    except AttributeError:          # a module tree that is not the reference's Unet3D layout
+        return False
+
+
+def _supports(unet, ok) -> bool:
     for mod in unet.modules():
         name = type(mod).__name__
         if name == "ResnetBlock":
