@@ -301,7 +301,11 @@ class Trainer(object):
             # "torch-autograd": every layer differentiates through torch ops; "hip-resnet": the ResnetBlocks (and the weight
             # gradients of init_conv / final_conv) run forward and backward on the HIP kernels (train_hip.py); "hip": the
             # temporal, linear and spatial attention layers and the Downsample / Upsample convolutions too
-            self.model.denoise_fn.train_backend = self.train_backend
+            backend = self.train_backend
+            if backend == "auto":      # the HIP layers when the model's shapes allow them, else torch ops throughout
+                from . import train_hip
+                backend = "hip" if (dev.type == "cuda" and train_hip.supports(self.model.denoise_fn)) else "torch-autograd"
+            self.model.denoise_fn.train_backend = backend
         loss_mod = _LossModule(self.model, self.null_frame_cond_prob)
         if self.distributed:
             loss_mod = nn.parallel.DistributedDataParallel(
