@@ -84,6 +84,42 @@ def cpu_baseline(batch, steps):
             "denoise_steps_per_s": steps_per_s}
 
 
+def train_step_line(device, steps=5):
+    """BASELINE configs[4]: loss forward + backward of Unet3D(dim=128, channels=3) on (1,3,16,128,128)
+    (reference vdp.py:1146-1161, 1451), on the HIP training kernels and on torch ops, both under bf16 autocast.
+    Reported beside the sampling metric, outside its timed region."""
+    import torch.nn.functional as F
+    from video_diffusion_amd import Unet3D
+    torch.manual_seed(0)
+    unet = Unet3D(dim=128, dim_mults=(1, 2, 4, 8), channels=3).to(device)
+    x = torch.randn(1, 3, 16, 128, 128, device=device)
+    noise = torch.randn_like(x)
+    t = torch.randint(0, TIMESTEPS, (1,), device=device)
+
+    def step(backend):
+        unet.train_backend = backend
+        for p in unet.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = F.l1_loss(unet(x, t).float(), noise)
+        loss.backward()
+        return loss
+
+    out = {"workload": "BASELINE configs[4]: Unet3D(dim=128,dim_mults=(1,2,4,8),channels=3) l1 loss forward + backward on "
+                       "x=(1,3,16,128,128), bf16 autocast, random-init weights, no optimizer step", "steps": steps}
+    for key, backend in (("hip_ms", "hip"), ("torch_ops_ms", "torch-autograd")):
+        for _ in range(2):
+            step(backend)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(backend)
+        torch.cuda.synchronize()
+        out[key] = round((time.perf_counter() - t0) / steps * 1e3, 2)
+    out["samples_per_s"] = round(1e3 / out["hip_ms"], 2)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +130,7 @@ def main():
                     help="total videos over all GPUs (strong scaling; 256 = BASELINE configs[2]); overrides --batch")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the real 1000-step loop after the timed steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the configs[4] training-step line")
     ap.add_argument("--parts", type=int, default=None,
                     help="concurrent sub-batches one forward is run as (default: the library's choice)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
@@ -354,6 +391,8 @@ def main():
             "videos_per_s_measured": None if full_loop_s is None else round(B * world / full_loop_s, 4),
             "roofline": roofline, "breakdown_ms_per_step": breakdown,
         }
+        if world == 1 and not args.no_train_step:
+            out["train_step"] = train_step_line(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch=16, steps=3)
         print(json.dumps(out), flush=True)
