@@ -496,3 +496,42 @@ def test_input_gradient_alone_skips_the_weight_gradients():
     m.train_backend = None
     assert all(p.grad is None for p in m.parameters())
     assert rel_err(gx, xa.grad) < 1e-6
+
+
+def test_bf16_activation_stream_between_hip_layers():
+    """A HIP layer answers a bf16 activation with a bf16 view of its own output rows (no cast, no copy on either side)
+    and a float one in float, with the same bits; a layer that falls back to torch ops inside the stream (here the
+    focus-masked temporal attention, vdp.py:590-600) is widened and narrowed around it, also outside autocast."""
+    from tests.helpers import inp, make_unet
+    from video_diffusion_amd import train_hip
+    m = make_unet(salt=4, dim=64, dim_mults=(1, 2), channels=3).to(DEV)
+    rb = m.downs[0][0]
+    x = inp("stream.x", (1, 64, 2, 16, 16)).to(DEV)
+    temb = inp("stream.t", (1, 512)).to(DEV)
+    xb = x.to(torch.bfloat16).requires_grad_(True)
+    yb = train_hip.resnet_block(rb, xb, temb)
+    yf = train_hip.resnet_block(rb, xb.detach().float(), temb)
+    assert yb.dtype == torch.bfloat16 and yf.dtype == torch.float32 and torch.equal(yb.float(), yf)
+    rows = train_hip.to_rows(yb)
+    assert rows.data_ptr() == yb.data_ptr()                   # the next layer's rows ARE this layer's output
+    yb.float().square().mean().backward()
+    assert xb.grad.dtype == torch.bfloat16 and bool(torch.isfinite(xb.grad.float()).all())
+
+    xi = inp("stream.img", (2, 3, 4, 16, 16)).to(DEV)
+    t = torch.tensor([5, 900], device=DEV)
+    focus = torch.tensor([True, False], device=DEV)
+
+    def run(backend):
+        m.train_backend = backend
+        for p in m.parameters():
+            p.grad = None
+        out = m(xi, t, focus_present_mask=focus)
+        out.square().mean().backward()
+        m.train_backend = None
+        return out.detach(), torch.cat([p.grad.flatten() for _, p in sorted(m.named_parameters()) if p.grad is not None])
+
+    o_ref, g_ref = run("torch-autograd")
+    o_hip, g_hip = run("hip")
+    assert o_hip.dtype == torch.float32
+    assert record("stream.focus.out", rel_err(o_hip, o_ref), 2e-2) < 2e-2
+    assert record("stream.focus.param_grads", rel_err(g_hip, g_ref), 5e-2) < 5e-2

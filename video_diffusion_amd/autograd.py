@@ -96,6 +96,14 @@ def _attention(att, x, pos_bias=None, focus=None):
 _HIP_ATTN = False       # train_backend == "hip": the temporal attention layers too
 
 
+def _torch_ops(fn, x):
+    # a layer that runs as torch ops; with the "hip" backend x may belong to the bf16 activation stream of the HIP layers
+    if x.dtype != torch.bfloat16:
+        return fn(x)
+    from .train_hip import torch_ops
+    return torch_ops(fn, x)
+
+
 def _rot_tables(rot, nf, device):
     if rot is None:
         return None
@@ -111,6 +119,10 @@ def _temporal(res, x, pos_bias, focus=None):
         from .train_hip import temporal_attention     # forward and backward on the HIP kernels
         att = res.fn.fn.fn
         return temporal_attention(res, x, pos_bias, _rot_tables(getattr(att, "rotary_emb", None), x.shape[2], x.device))
+    return _torch_ops(lambda x: _temporal_ops(res, x, pos_bias, focus), x)
+
+
+def _temporal_ops(res, x, pos_bias, focus):
     b, c, f, h, w = x.shape
     y = _chan_layernorm(x, res.fn.norm).permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
     o = _attention(res.fn.fn.fn, y, pos_bias, focus)
@@ -122,6 +134,10 @@ def _spatial(res, x):
     if _HIP_ATTN and x.is_cuda and x.shape[3] * x.shape[4] <= 256:
         from .train_hip import spatial_attention      # forward and backward on the HIP kernels
         return spatial_attention(res, x)
+    return _torch_ops(lambda x: _spatial_ops(res, x), x)
+
+
+def _spatial_ops(res, x):
     b, c, f, h, w = x.shape
     y = _chan_layernorm(x, res.fn.norm).permute(0, 2, 3, 4, 1).reshape(b, f, h * w, c)
     o = _attention(res.fn.fn.fn, y)
@@ -133,7 +149,7 @@ def _resample(mod, x):
     if _HIP_ATTN and x.is_cuda and not isinstance(mod, torch.nn.Identity):
         from .train_hip import resample
         return resample(mod, x)
-    return mod(x)
+    return x if isinstance(mod, torch.nn.Identity) else _torch_ops(mod, x)
 
 
 def _linear_attention(res, x):
@@ -142,6 +158,12 @@ def _linear_attention(res, x):
     if _HIP_ATTN and x.is_cuda and isinstance(sl.to_qkv, torch.nn.Conv2d):
         from .train_hip import spatial_linear_attention     # forward and backward on the HIP kernels
         return spatial_linear_attention(res, x)
+    return _torch_ops(lambda x: _linear_attention_ops(res, x), x)
+
+
+def _linear_attention_ops(res, x):
+    sl = res.fn.fn
+    b, c, f, h, w = x.shape
     y = _chan_layernorm(x, res.fn.norm)
     if isinstance(sl.to_qkv, torch.nn.Linear):
         # SpatioTemporalAttention, version1diffusion.py:325-345
@@ -159,6 +181,10 @@ def _linear_attention(res, x):
 
 
 def _cross_attention(res, x, ctx):
+    return _torch_ops(lambda x: _cross_attention_ops(res, x, ctx), x)
+
+
+def _cross_attention_ops(res, x, ctx):
     # Residual(PreNorm(CrossAttention)), vdp.py:480-528
     ca = res.fn.fn
     b, c, f, h, w = x.shape
@@ -216,6 +242,9 @@ def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null
     if _HIP_RESNET and x.is_cuda:
         from .train_hip import init_conv        # torch forward, weight gradient on the HIP kernels
         x = init_conv(unet.init_conv, x)
+        if _HIP_ATTN:
+            # from here to final_conv the activations stay bf16: every HIP layer hands a view of its output rows to the next
+            x = x.to(torch.bfloat16)
     else:
         x = unet.init_conv(x)
     x = _temporal(unet.init_temporal_attn, x, bias)

@@ -16,6 +16,7 @@ There is no fallback: a shape the kernels do not take raises.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 
 import torch
 import torch.nn.functional as F
@@ -38,8 +39,36 @@ def to_rows(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).permute(0, 2, 3, 4, 1).reshape(-1, x.shape[1]).contiguous()
 
 
-def from_rows(r: torch.Tensor, b: int, f: int, h: int, w: int) -> torch.Tensor:
-    return r.view(b, f, h, w, r.shape[1]).permute(0, 4, 1, 2, 3).float()
+def from_rows(r: torch.Tensor, b: int, f: int, h: int, w: int, dtype=torch.float32) -> torch.Tensor:
+    """bf16 rows -> (B, C, F, H, W) of `dtype`; for bfloat16 a view of the rows themselves (no pass over the data)."""
+    return r.view(b, f, h, w, r.shape[1]).permute(0, 4, 1, 2, 3).to(dtype)
+
+
+def _act_dtype(x: torch.Tensor):
+    """The layers keep the activation dtype of their input: a bf16 activation (a view of the previous layer's rows) gives
+    a bf16 view of this layer's rows, and between two such layers no cast or copy runs in either direction; anything
+    else is answered in float."""
+    return torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32
+
+
+def _plain(fn):
+    """forward / backward of a Function outside autocast, with its inputs left as they come (torch.amp.custom_fwd with
+    cast_inputs would widen a bf16 activation again); parameters are float whatever the autocast state."""
+    @functools.wraps(fn)
+    def inner(*args):
+        with torch.autocast("cuda", enabled=False):
+            return fn(*args)
+    return inner
+
+
+def torch_ops(fn, *xs):
+    """fn(*xs) for a layer that runs as torch ops beside the HIP layers: activations of a bf16 stream are widened first
+    (outside autocast the layer's float parameters would not take them), the result goes back to the stream's dtype."""
+    if xs[0].dtype != torch.bfloat16:
+        return fn(*xs)
+    if not torch.is_autocast_enabled():
+        xs = tuple(x.float() for x in xs)
+    return fn(*xs).to(torch.bfloat16)
 
 
 class DevPack:
@@ -166,7 +195,7 @@ class ResnetBlockFn(torch.autograd.Function):
     scale / shift: float [B][Cout] (the chunks of the block's time MLP output) or None; wres / bres None = identity."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_plain
     def forward(ctx, x, scale, shift, w1, b1, g1, w2, b2, g2, wres, bres, with_res=True):
         # with_res = False: block2(block1(x)) alone, for callers that put a layer between the blocks and the residual
         if not x.is_cuda:
@@ -196,10 +225,11 @@ class ResnetBlockFn(torch.autograd.Function):
         ctx.save_for_backward(xr, y1, h1, y2, g1v, g2v, scale_c, shift_c, w1, w2, wres)
         ctx.dims = (b, cin, cout, f, h, w)
         ctx.with_res = with_res
-        return from_rows(out, b, f, h, w)
+        ctx.act = _act_dtype(x)
+        return from_rows(out, b, f, h, w, ctx.act)
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    @_plain
     def backward(ctx, dout):
         xr, y1, h1, y2, g1v, g2v, scale_c, shift_c, w1, w2, wres = ctx.saved_tensors
         b, cin, cout, f, h, w = ctx.dims
@@ -229,7 +259,7 @@ class ResnetBlockFn(torch.autograd.Function):
             dbres = colsum_rows(do) if need[10] else None
             dx_res = conv_rows(do, DevPack(wres, True), None, frames, f, h, w)
         dx = conv_rows(dy1, DevPack(w1, True), None, frames, f, h, w, residual=dx_res)
-        return (from_rows(dx, b, f, h, w), dscale, dshift, dw1, db1, dg1.view(cout, 1, 1, 1), dw2, db2,
+        return (from_rows(dx, b, f, h, w, ctx.act), dscale, dshift, dw1, db1, dg1.view(cout, 1, 1, 1), dw2, db2,
                 dg2.view(cout, 1, 1, 1), dwres, dbres, None)
 
 
@@ -238,21 +268,21 @@ class InitConvFn(torch.autograd.Function):
     convolution torch falls back to for a 3-channel (1,7,7) weight gradient takes 40 ms at 16 x 128 x 128)."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_plain
     def forward(ctx, x, weight, bias, pad):
         ctx.save_for_backward(x, weight)
         ctx.pad = pad
-        return F.conv3d(x, weight, bias, padding=(0, pad, pad))
+        return F.conv3d(x.float(), weight, bias, padding=(0, pad, pad))
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    @_plain
     def backward(ctx, dout):
         x, weight = ctx.saved_tensors
         b, cin, f, h, w = x.shape
         cout, kh, kw = weight.shape[0], weight.shape[3], weight.shape[4]
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.nn.grad.conv3d_input(x.shape, weight, dout.float(), padding=(0, ctx.pad, ctx.pad))
+            dx = torch.nn.grad.conv3d_input(x.shape, weight, dout.float(), padding=(0, ctx.pad, ctx.pad)).to(x.dtype)
         cpad = (cin + 7) // 8 * 8                      # rows need a multiple of 8 channels
         xr = torch.zeros(b * f * h * w, cpad, device=x.device, dtype=torch.bfloat16)
         xr[:, :cin] = x.permute(0, 2, 3, 4, 1).reshape(-1, cin)
@@ -274,20 +304,22 @@ class PointwiseConvFn(torch.autograd.Function):
     bf16 autocast takes 40 ms at 16 x 128 x 128)."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_plain
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         w2 = weight.reshape(weight.shape[0], weight.shape[1])
-        return torch.einsum("oc,bcfhw->bofhw", w2, x) + bias.view(1, -1, 1, 1, 1)
+        return torch.einsum("oc,bcfhw->bofhw", w2, x.float()) + bias.view(1, -1, 1, 1, 1)
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    @_plain
     def backward(ctx, dout):
         x, weight = ctx.saved_tensors
         b, cin, f, h, w = x.shape
         cout = weight.shape[0]
         dout = dout.float()
-        dx = torch.einsum("oc,bofhw->bcfhw", weight.reshape(cout, cin), dout) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.einsum("oc,bofhw->bcfhw", weight.reshape(cout, cin), dout).to(x.dtype)
         cpad = (cout + 7) // 8 * 8
         dr = torch.zeros(b * f * h * w, cpad, device=x.device, dtype=torch.bfloat16)
         dr[:, :cout] = dout.permute(0, 2, 3, 4, 1).reshape(-1, cout)
@@ -314,7 +346,7 @@ def resnet_block(rb, x: torch.Tensor, temb) -> torch.Tensor:
             rb.block2.proj.weight, rb.block2.proj.bias, rb.block2.norm.gamma)
     tconv = getattr(rb, "temporal_conv", None)
     if tconv is not None:
-        return tconv(ResnetBlockFn.apply(*args, None, None, False)) + rc(x)
+        return torch_ops(lambda y, xin: tconv(y) + rc(xin), ResnetBlockFn.apply(*args, None, None, False), x)
     return ResnetBlockFn.apply(*args, wres, bres)
 
 
@@ -360,7 +392,7 @@ class TemporalAttnFn(torch.autograd.Function):
     wout (C, heads*32); bias float [heads][F][F] (may require grad); cos / sin float [F][16] or None."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_plain
     def forward(ctx, x, gamma, wqkv, wout, bias, cos, sin, heads, scale, eps, spatial=False):
         if not x.is_cuda:
             raise _lib.VdmiError("the HIP training backend needs CUDA (HIP) tensors; there is no CPU path")
@@ -384,10 +416,11 @@ class TemporalAttnFn(torch.autograd.Function):
         y = conv_rows(o, _linear_pack(wout.detach().contiguous(), False), None, b * f, f, h, w, residual=xr)
         ctx.save_for_backward(xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin)
         ctx.meta = (b, c, f, h, w, heads, scale, eps, core)
-        return from_rows(y, b, f, h, w)
+        ctx.act = _act_dtype(x)
+        return from_rows(y, b, f, h, w, ctx.act)
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    @_plain
     def backward(ctx, dy):
         xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin = ctx.saved_tensors
         b, c, f, h, w, heads, scale, eps, core = ctx.meta
@@ -419,7 +452,7 @@ class TemporalAttnFn(torch.autograd.Function):
         dx = torch.empty_like(xr)
         check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
                                           _stream()), "vdmi_layernorm_rows_bwd")
-        return from_rows(dx, b, f, h, w), dgamma, dwqkv, dwout, dbias, None, None, None, None, None, None
+        return from_rows(dx, b, f, h, w, ctx.act), dgamma, dwqkv, dwout, dbias, None, None, None, None, None, None
 
 
 def spatial_attention(res, x: torch.Tensor) -> torch.Tensor:
@@ -535,17 +568,18 @@ def strided_wgrad(big: torch.Tensor, small: torch.Tensor, frames: int, h: int, w
 
 class DownsampleFn(torch.autograd.Function):
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_plain
     def forward(ctx, x, weight, bias):
         b, c, f, h, w = x.shape
         xr = to_rows(x)
         y = down_conv_rows(xr, weight, bias.detach().float().contiguous(), b * f, f, h, w)
         ctx.save_for_backward(xr, weight)
         ctx.dims = (b, f, h, w)
-        return from_rows(y, b, f, h // 2, w // 2)
+        ctx.act = _act_dtype(x)
+        return from_rows(y, b, f, h // 2, w // 2, ctx.act)
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    @_plain
     def backward(ctx, dy):
         xr, weight = ctx.saved_tensors
         b, f, h, w = ctx.dims
@@ -553,22 +587,23 @@ class DownsampleFn(torch.autograd.Function):
         # the input gradient of a strided convolution is the transposed convolution with the same weight tensor
         dx = up_conv_rows(dyr, weight, None, b * f, f, h // 2, w // 2)
         dw = strided_wgrad(xr, dyr, b * f, h, w) if ctx.needs_input_grad[1] else None
-        return from_rows(dx, b, f, h, w), dw, colsum_rows(dyr) if ctx.needs_input_grad[2] else None
+        return from_rows(dx, b, f, h, w, ctx.act), dw, colsum_rows(dyr) if ctx.needs_input_grad[2] else None
 
 
 class UpsampleFn(torch.autograd.Function):
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_plain
     def forward(ctx, x, weight, bias):
         b, c, f, h, w = x.shape
         xr = to_rows(x)
         y = up_conv_rows(xr, weight, bias.detach().float().contiguous(), b * f, f, h, w)
         ctx.save_for_backward(xr, weight)
         ctx.dims = (b, f, h, w)
-        return from_rows(y, b, f, 2 * h, 2 * w)
+        ctx.act = _act_dtype(x)
+        return from_rows(y, b, f, 2 * h, 2 * w, ctx.act)
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    @_plain
     def backward(ctx, dy):
         xr, weight = ctx.saved_tensors
         b, f, h, w = ctx.dims
@@ -576,7 +611,7 @@ class UpsampleFn(torch.autograd.Function):
         # ... and the input gradient of the transposed convolution is the strided convolution with the same weight tensor
         dx = down_conv_rows(dyr, weight, None, b * f, f, 2 * h, 2 * w)
         dw = strided_wgrad(dyr, xr, b * f, 2 * h, 2 * w) if ctx.needs_input_grad[1] else None
-        return from_rows(dx, b, f, h, w), dw, colsum_rows(dyr) if ctx.needs_input_grad[2] else None
+        return from_rows(dx, b, f, h, w, ctx.act), dw, colsum_rows(dyr) if ctx.needs_input_grad[2] else None
 
 
 def resample(mod, x: torch.Tensor) -> torch.Tensor:
@@ -607,7 +642,7 @@ class SlaFn(torch.autograd.Function):
     bout (C).  Forward and backward on the HIP kernels."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_plain
     def forward(ctx, x, gamma, wqkv, wout, bout, heads, scale, eps):
         if not x.is_cuda:
             raise _lib.VdmiError("the HIP training backend needs CUDA (HIP) tensors; there is no CPU path")
@@ -631,10 +666,11 @@ class SlaFn(torch.autograd.Function):
                       residual=xr)
         ctx.save_for_backward(xr, xh, qkv, qt, out, p_ctx, wp, wqkv, wout, gamma)
         ctx.meta = (b, c, f, h, w, heads, scale, eps)
-        return from_rows(y, b, f, h, w)
+        ctx.act = _act_dtype(x)
+        return from_rows(y, b, f, h, w, ctx.act)
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    @_plain
     def backward(ctx, dy):
         xr, xh, qkv, qt, out, p_ctx, wp, wqkv, wout, gamma = ctx.saved_tensors
         b, c, f, h, w, heads, scale, eps = ctx.meta
@@ -663,7 +699,7 @@ class SlaFn(torch.autograd.Function):
         dx = torch.empty_like(xr)
         check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
                                           _stream()), "vdmi_layernorm_rows_bwd")
-        return (from_rows(dx, b, f, h, w), dgamma, dwqkv, dwout, colsum_rows(dyr) if need[4] else None, None, None, None)
+        return (from_rows(dx, b, f, h, w, ctx.act), dgamma, dwqkv, dwout, colsum_rows(dyr) if need[4] else None, None, None, None)
 
 
 def spatial_linear_attention(res, x: torch.Tensor) -> torch.Tensor:
