@@ -414,8 +414,8 @@ size_t vdmi_rows_transpose_elems(int c, int nf, int64_t hw);                    
 int vdmi_rows_transpose(const void* rows, int ld, int c_off, int c, int nf, int64_t hw, void* out, vdmi_stream stream);
 
 /* Weight gradient of a stride-1 (1,k,k) convolution (torch's conv3d weight gradient, vdp.py:415, 439):
- *   dw[co][cin_off + ci][tap] += sum over frames f and pixels p of dy[f][p][co] * x[f][p + (dy,dx)_tap][ci]
- * (zero outside the image).  xT: vdmi_rows_transpose of the input rows (cin channels), dyT: of the output-gradient
+ *   dw[co][cin_off + ci][tap] = sum over frames f and pixels p of dy[f][p][co] * x[f][p + (dy,dx)_tap][ci]
+ * (zero outside the image; written, not accumulated: dw needs no initialisation).  xT: vdmi_rows_transpose of the input rows (cin channels), dyT: of the output-gradient
  * rows (cout channels), both over nf frames of h x w pixels; dw float [cout][cin_total][ntaps]; ntaps 1, or 9 with
  * the row-major tap table (ky - 1, kx - 1).  workspace: vdmi_conv_wgrad_workspace_bytes() bytes (partial tiles of
  * the workgroups that share a (co, ci) tile, added by a second launch in a fixed order: results are repeatable). */
@@ -426,7 +426,7 @@ int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int cin, int cou
 
 /* The same gradient for a (1,kh,kw) "same" convolution with few input channels (Unet3D.init_conv, vdp.py:644: 3 -> dim,
  * 7 x 7): a column of the contraction is a (ci, ky, kx) triple, so no lane idles on padding channels.  kh, kw odd;
- * dw float [cout][cin][kh][kw], ACCUMULATED; workspace: vdmi_conv_wgrad_gather_workspace_bytes() bytes. */
+ * dw float [cout][cin][kh][kw], written (not accumulated); workspace: vdmi_conv_wgrad_gather_workspace_bytes() bytes. */
 size_t vdmi_conv_wgrad_gather_workspace_bytes(int cin, int cout, int nf, int h, int w, int kh, int kw);   /* HOST */
 int vdmi_conv_wgrad_gather(const void* xT, const void* dyT, float* dw, int cin, int cout, int nf, int h, int w,
                            int kh, int kw, void* workspace, vdmi_stream stream);

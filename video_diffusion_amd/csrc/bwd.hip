@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void rows_transpose_kernel(const __bf16* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// wgrad: dW[co][cin_off + ci][tap] += sum over (pixel, frame) of dyT[co][p][f] * xT[ci][p + off(tap)][f]
+// wgrad: dW[co][cin_off + ci][tap] = sum over (pixel, frame) of dyT[co][p][f] * xT[ci][p + off(tap)][f]
 // A workgroup = 4 waves = a 64 x 64 (co, ci) tile; blockIdx.z = a share of the (frame block, pixel) units.
 // ------------------------------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void wgrad_gather_kernel(const WgradGatherArgs
         part[((wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + (wave >> 1) * 32 + l31] = acc0[r] + acc1[r];
 }
 
-// dw[co][cin_off + ci][t] += sum over the nz partial tiles of a (co, ci) tile (one thread per element: deterministic)
+// dw[co][cin_off + ci][t] = sum over the nz partial tiles of a (co, ci) tile (one thread per element: deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nz, int tx, int ty, int nt,
                                                            float* __restrict__ dw, int cout, int cin, int cin_total,
                                                            int cin_off) {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (co >= cout || ci >= cin) return;
     float sum = 0.f;
     for (int z = 0; z < nz; ++z) sum += part[(size_t)z * per_z + e];
-    dw[((size_t)co * cin_total + cin_off + ci) * nt + t] += sum;
+    dw[((size_t)co * cin_total + cin_off + ci) * nt + t] = sum;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -146,7 +146,7 @@ def conv_wgrad(x_t: torch.Tensor, dy_t: torch.Tensor, cin: int, cout: int, nf: i
     """float32 (cout, cin, 1, k, k) weight gradient from the transposed operands; `tap`: the pixel offset of the
     one-tap form (dw[co][ci] = sum_p dy[p][co] x[p + tap][ci])."""
     k = 3 if ntaps == 9 else 1
-    dw = torch.zeros(cout, cin, 1, k, k, device=x_t.device, dtype=torch.float32)
+    dw = torch.empty(cout, cin, 1, k, k, device=x_t.device, dtype=torch.float32)
     taps = _TAPS_3x3 if ntaps == 9 else [tuple(tap)]
     dy = (C.c_int8 * ntaps)(*[t[0] for t in taps])
     dx = (C.c_int8 * ntaps)(*[t[1] for t in taps])
@@ -160,7 +160,7 @@ def conv_wgrad(x_t: torch.Tensor, dy_t: torch.Tensor, cin: int, cout: int, nf: i
 def conv_wgrad_gather(x_t, dy_t, cin, cout, nf, h, w, kh, kw) -> torch.Tensor:
     """float32 (cout, cin, 1, kh, kw) weight gradient of a small-cin convolution (init_conv)."""
     lib = _lib.lib()
-    dw = torch.zeros(cout, cin, 1, kh, kw, device=x_t.device, dtype=torch.float32)
+    dw = torch.empty(cout, cin, 1, kh, kw, device=x_t.device, dtype=torch.float32)
     ws = torch.empty(lib.vdmi_conv_wgrad_gather_workspace_bytes(cin, cout, nf, h, w, kh, kw), device=x_t.device,
                      dtype=torch.uint8)
     check(lib.vdmi_conv_wgrad_gather(x_t.data_ptr(), dy_t.data_ptr(), dw.data_ptr(), cin, cout, nf, h, w, kh, kw,
@@ -172,10 +172,13 @@ def rmsnorm_silu_bwd_rows(y, dh, gamma, scale, shift, batch, rows_per_batch, wan
     rows, c = y.shape
     dev = y.device
     dy = torch.empty_like(y)
-    dgamma = torch.zeros(c, device=dev, dtype=torch.float32)
-    dbias = torch.zeros(c, device=dev, dtype=torch.float32) if want_bias else None
-    dscale = torch.zeros(batch, c, device=dev, dtype=torch.float32) if scale is not None else None
-    dshift = torch.zeros(batch, c, device=dev, dtype=torch.float32) if scale is not None else None
+    # the kernel accumulates into all four: one zero fill, four views
+    nb = batch if scale is not None else 0
+    acc = torch.zeros(2 + 2 * nb, c, device=dev, dtype=torch.float32)
+    dgamma = acc[0]
+    dbias = acc[1] if want_bias else None
+    dscale = acc[2:2 + nb] if scale is not None else None
+    dshift = acc[2 + nb:] if scale is not None else None
     ptr = lambda t: None if t is None else t.data_ptr()
     check(_lib.lib().vdmi_rmsnorm_silu_bwd(
         y.data_ptr(), c, dh.data_ptr(), dh.shape[1], dy.data_ptr(), c, batch, rows_per_batch, c, gamma.data_ptr(),
