@@ -392,7 +392,10 @@ def main():
             "roofline": roofline, "breakdown_ms_per_step": breakdown,
         }
         if world == 1 and not args.no_train_step:
-            out["train_step"] = train_step_line(device)
+            try:
+                out["train_step"] = train_step_line(device)
+            except Exception as e:      # a side measurement: report the failure, keep the sampling line
+                out["train_step"] = {"failed": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch=16, steps=3)
         print(json.dumps(out), flush=True)
