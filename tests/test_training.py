@@ -271,3 +271,54 @@ def test_reconstruction_guidance_gradient_on_hip_kernels_matches_torch_ops():
     assert gd.denoise_fn.train_backend is None
     # measured 4.4e-2: the gradient runs backwards through a bf16 denoiser whose epsilon error the x0 prediction amplifies
     assert record("v1_guidance.hip_vs_torch", rel_err(g_hip, g_ref), 8e-2) < 8e-2
+
+
+def test_guidance_variant_gradient_path_matches_reference_and_oracle():
+    """guidance_variant.Unet3D with a gradient asked for (video_diffusion_guidance.py:725-761 differentiates the
+    reconstruction loss through the denoiser): the torch-op forward reproduces that file's own output (golden made by
+    oracle/make_golden_guidance.py) and its input gradient is the oracle's."""
+    from oracle import vdm_oracle as O, weightgen
+    from tests.helpers import golden, inp
+    from video_diffusion_amd import guidance_variant as GV
+    g = golden("guidance_tiny")
+    m = GV.Unet3D(dim=64, dim_mults=(1, 2), channels=4)
+    m.load_state_dict(weightgen.fill_state_dict(m.state_dict(), 4))
+    x = inp("g.x", tuple(int(v) for v in g["x_shape"])).requires_grad_(True)
+    t = torch.as_tensor(g["t"])
+    y = m(x, t)
+    assert rel_err(y.detach(), g["eps"]) < 1e-5
+    gx, = torch.autograd.grad(y.square().mean(), x)
+    cfg = O.UnetCfg(dim=64, dim_mults=(1, 2), channels=4, max_distance=300)
+    x2 = x.detach().clone().requires_grad_(True)
+    g2, = torch.autograd.grad(O.unet3d_guidance_forward(m.state_dict(), cfg, x2, t).square().mean(), x2)
+    assert rel_err(gx, g2) < 1e-4
+
+
+@pytest.mark.gpu
+def test_guidance_variant_reconstruction_guidance_on_the_gpu():
+    """The guidance sampler of video_diffusion_guidance.py on the GPU: the gradient step differentiates through torch ops
+    over the variant's parameters, the denoising step that follows runs on the HIP plan; the two forwards agree to the bf16
+    bar and the gradient equals the one computed on the CPU."""
+    from video_diffusion_amd import VAE, guidance_variant as GV
+    from tests.helpers import record
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    unet = GV.Unet3D(dim=64, dim_mults=(1, 2), channels=4)
+    vae = VAE(channels=3, latent_dim=4, base_dim=64)
+    gd = GV.GaussianDiffusion(unet.eval(), vae.eval(), image_size=32, num_frames=3, channels=3, timesteps=250)
+    z = torch.randn(2, 4, 3, 4, 4)
+    t = torch.tensor([40, 200])
+    prev = torch.rand(2, 3, 2, 32, 32)
+    g_cpu = GV.temporal_consistency_guidance(gd, prev, 2, w_r=3.0)(z, t)
+    gd = gd.to(dev)
+    zd, td = z.to(dev), t.to(dev)
+    g_gpu = GV.temporal_consistency_guidance(gd, prev.to(dev), 2, w_r=3.0)(zd, td)
+    assert bool(torch.isfinite(g_gpu).all()) and float(g_gpu.abs().max()) > 0
+    assert record("gv_guidance.gpu_vs_cpu", rel_err(g_gpu.cpu(), g_cpu), 1e-3) < 1e-3
+    with torch.no_grad():
+        e_hip = gd.denoise_fn(zd, td)
+    e_ops = gd.denoise_fn(zd.clone().requires_grad_(True), td).detach()
+    assert record("gv_guidance.hip_forward_vs_torch_ops", rel_err(e_hip, e_ops), 2e-2) < 2e-2
+    x = gd.p_sample(zd, td, guidance_fn=GV.temporal_consistency_guidance(gd, prev.to(dev), 2, w_r=3.0), guidance_scale=1.0,
+                    noise=torch.zeros_like(zd))
+    assert x.shape == zd.shape and bool(torch.isfinite(x).all())

@@ -292,3 +292,56 @@ def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null
         from .train_hip import pointwise_conv   # weight gradient on the HIP kernels
         return pointwise_conv(unet.final_conv[1], x)
     return unet.final_conv[1](x)
+
+
+def guidance_variant_forward(unet, x, time):
+    """Unet3D.forward of the reference's video_diffusion_guidance.py (:596-635) as differentiable torch ops over the
+    parameters of a guidance_variant.Unet3D: the reference's guidance sampler differentiates the reconstruction loss
+    through this denoiser (video_diffusion_guidance.py:725-761, 860-900).  Used only when a gradient is asked for;
+    sampling runs on the HIP plan."""
+    bias = _pos_bias(unet, x.shape[2], x.device)
+
+    def tattn(res, x):
+        # Residual(PreNorm(TemporalAttention)), :390-428: attention over the frames of every position
+        b, c, f, h, w = x.shape
+        y = _chan_layernorm(x, res.fn.norm).permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
+        return _attention(res.fn.fn, y, bias).reshape(b, h, w, f, c).permute(0, 4, 3, 1, 2) + x
+
+    def sattn(res, x):
+        # Residual(PreNorm(SpatialAttention)), :431-459: attention over the positions of every frame
+        b, c, f, h, w = x.shape
+        y = _chan_layernorm(x, res.fn.norm).permute(0, 2, 3, 4, 1).reshape(b, f, h * w, c)
+        return _attention(res.fn.fn, y).reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3) + x
+
+    def ts(tb, x):
+        # TemporalSpatialBlock, :334-344
+        h = F.silu(tb.temporal_norm(tb.temporal_conv(x)))
+        return F.silu(tb.spatial_norm(tb.spatial_conv(h)))
+
+    def rb(blk, x, temb=None):
+        # ResnetBlock, :370-388: the time embedding acts between the two blocks
+        res = blk.res_conv(x)
+        h = ts(blk.ts_block1, x)
+        if blk.mlp is not None and temb is not None:
+            scale, shift = blk.mlp(temb)[:, :, None, None, None].chunk(2, dim=1)
+            h = h * (scale + 1) + shift
+        return ts(blk.ts_block2, h) + res
+
+    x = tattn(unet.init_temporal_attn, unet.init_conv(x))
+    r = x
+    half = unet.dim // 2
+    freq = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
+    ang = time[:, None] * freq[None, :]
+    t = unet.time_mlp[3](F.gelu(unet.time_mlp[1](torch.cat((ang.sin(), ang.cos()), dim=-1))))
+    skips = []
+    for b1, b2, ta, sa, down in unet.downs:
+        x = sattn(sa, tattn(ta, rb(b2, rb(b1, x, t), t)))
+        skips.append(x)
+        x = down(x)
+    x = rb(unet.mid_block1, x, t)
+    x = rb(unet.mid_block2, sattn(unet.mid_spatial_attn, tattn(unet.mid_temporal_attn, x)), t)
+    for b1, b2, ta, sa, up in unet.ups:
+        x = torch.cat((x, skips.pop()), dim=1)
+        x = up(sattn(sa, tattn(ta, rb(b2, rb(b1, x, t), t))))
+    x = torch.cat((x, r), dim=1)
+    return unet.final_conv[1](rb(unet.final_conv[0], x))         # :591-594, 635: the final block gets no embedding

@@ -138,7 +138,10 @@ class Unet3D(nn.Module):
 
     def forward(self, x, time):
         if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("the HIP denoiser is forward-only")
+            # a gradient with respect to x_t (the guidance sampler, video_diffusion_guidance.py:725-761): torch ops over the
+            # same parameters, as the reference differentiates; the HIP plan of this variant is forward-only
+            from .autograd import guidance_variant_forward
+            return guidance_variant_forward(self, x, time)
         return self.engine().forward(x, time)
 
 
