@@ -1,11 +1,14 @@
 """Differentiable execution of Unet3D for training.
 
-Apart from ResnetBlock (train_hip.py, opt-in) the HIP kernels are forward-only.  The reference trains through PyTorch autograd (its Trainer,
-video_diffusion_pytorch/video_diffusion_pytorch.py:1414-1453, calls loss.backward() on torch ops); this module
-runs the same arithmetic as torch ops over the module's own parameters so that `loss.backward()`, the optimizer
-and DistributedDataParallel work unchanged.  It is never used for sampling: `Unet3D.forward` only comes here
-when gradients are required AND the owner opted in with `unet.train_backend = "torch-autograd"` (the Trainer
-does); otherwise a forward that needs gradients raises.  fp32 throughout, like the reference.
+The reference trains through PyTorch autograd (its Trainer, video_diffusion_pytorch/video_diffusion_pytorch.py:1414-1453,
+calls loss.backward() on torch ops); this module runs the same arithmetic as torch ops over the module's own
+parameters so that `loss.backward()`, the optimizer and DistributedDataParallel work unchanged.  It is never used for
+sampling: `Unet3D.forward` only comes here when gradients are required AND the owner opted in with
+`unet.train_backend` (the Trainer does); otherwise a forward that needs gradients raises.  Backends:
+"torch-autograd" - every layer a torch op, fp32 like the reference; "hip-resnet" - the ResnetBlocks forward and backward on
+the HIP kernels (train_hip.py); "hip" - the temporal, linear and mid-block spatial attention layers and the resampling
+convolutions too, with bf16 activations between the layers (what stays a torch op: embeddings, cross-attention,
+focus-masked temporal attention, the forward of init_conv / final_conv).
 
 Line references: vdp.py = video_diffusion_pytorch/video_diffusion_pytorch.py of the reference.
 """

@@ -372,6 +372,9 @@ def _supports(unet, ok) -> bool:
         elif name in ("Attention", "SpatialLinearAttention", "SpatioTemporalAttention"):
             if getattr(mod, "dim_head", 32) != 32:
                 return False
+            rot = getattr(mod, "rotary_emb", None)
+            if rot is not None and getattr(rot, "convention", "half") != "half":
+                return False            # the attention backward kernel rotates half-split pairs only
         elif name == "PreNorm":
             if not ok(mod.norm.gamma.numel()):
                 return False

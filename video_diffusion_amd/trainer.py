@@ -2,9 +2,10 @@
 arguments, GIF dataset, EMA, checkpoint format (`model-{milestone}.pt` with keys step/model/ema/scaler/opt),
 the training loop and the periodic sample + save.
 
-Gradients come from PyTorch autograd over torch ops (`Unet3D.train_backend = "torch-autograd"`, autograd.py) —
-the HIP kernels are forward-only and serve the sampling the loop does at every milestone.  What is new against
-the reference: data-parallel training when launched with one process per GPU (WORLD_SIZE > 1): the loss module
+Gradients come from PyTorch autograd: by default over torch ops (`Unet3D.train_backend = "torch-autograd"`,
+autograd.py), with `trainer.train_backend = "hip"` / "auto" (or VDMI_TRAIN_BACKEND) through autograd Functions whose
+forward and backward are the HIP kernels (train_hip.py); the sampling the loop does at every milestone always runs on
+the HIP plan.  What is new against the reference: data-parallel training when launched with one process per GPU (WORLD_SIZE > 1): the loss module
 is wrapped in DistributedDataParallel (bucketed gradient all-reduce over RCCL, overlapped with backward; unused
 parameters such as the frame cross-attention layers of an unconditioned batch are detected), each rank reads its
 own shard of the dataset, rank 0 samples and saves; and the EMA update is one fused multi-tensor lerp instead

@@ -12,7 +12,8 @@ Class names, constructor signatures and state-dict keys follow that file.  The t
 3-tap vdmi_tapgemm over the (frame, position) view of the rows; the full attention reuses the
 cross-attention core (vdmi_xattn_pack_kv / vdmi_xattn_core) with the layer's own keys and values.
 Reconstruction guidance (`temporal_consistency_guidance`, :707-747) differentiates through the denoiser and
-the VAE decoder; that derivative is taken with PyTorch autograd ops (the HIP kernels are forward-only).
+the VAE decoder: PyTorch autograd, through the HIP training kernels where the denoiser's shapes allow
+(train_hip.supports), else through torch ops.
 """
 from __future__ import annotations
 
