@@ -109,7 +109,7 @@ class GaussianDiffusion(_diffusion.GaussianDiffusion):
         return self.denoise_fn(x, t)                       # :557
 
     def p_losses(self, x_start, t, noise=None):
-        # :633-649 (forward value only: the HIP denoiser has no backward)
+        # :633-649 (differentiable when the denoiser's train_backend is set, as for the packaged model)
         x_start_normalized = (x_start * 2.0 - 1.0).clamp(-1, 1)
         self.vae.eval()
         with torch.no_grad():
