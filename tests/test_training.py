@@ -292,6 +292,14 @@ def test_guidance_variant_gradient_path_matches_reference_and_oracle():
     x2 = x.detach().clone().requires_grad_(True)
     g2, = torch.autograd.grad(O.unet3d_guidance_forward(m.state_dict(), cfg, x2, t).square().mean(), x2)
     assert rel_err(gx, g2) < 1e-4
+    # training: parameter gradients with the backend the Trainer sets; anything else is refused, not ignored
+    m.train_backend = "torch-autograd"
+    m(x.detach(), t).square().mean().backward()
+    missing = [n for n, p in m.named_parameters() if p.grad is None]
+    assert all(n.startswith("final_conv.0.mlp") for n in missing), missing      # that block runs without the embedding
+    m.train_backend = "hip"
+    with pytest.raises(Exception, match="torch ops only"):
+        m(x.detach(), t)
 
 
 @pytest.mark.gpu

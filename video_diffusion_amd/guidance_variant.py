@@ -122,6 +122,7 @@ class Unet3D(nn.Module):
         self.out_dim = out_dim
         self.final_conv = nn.Sequential(rb(dim * 2, dim), nn.Conv3d(dim, out_dim, 1))
         self._engine = None
+        self.train_backend = None       # "torch-autograd" (the Trainer sets it): forward as differentiable torch ops
 
     def __deepcopy__(self, memo):
         import copy
@@ -137,9 +138,13 @@ class Unet3D(nn.Module):
         return self._engine
 
     def forward(self, x, time):
-        if torch.is_grad_enabled() and x.requires_grad:
-            # a gradient with respect to x_t (the guidance sampler, video_diffusion_guidance.py:725-761): torch ops over the
-            # same parameters, as the reference differentiates; the HIP plan of this variant is forward-only
+        if torch.is_grad_enabled() and (x.requires_grad or self.train_backend is not None):
+            # a gradient with respect to x_t (the guidance sampler, video_diffusion_guidance.py:725-761) or to the
+            # parameters (training): torch ops over the same parameters, as the reference differentiates; the HIP plan of
+            # this variant is forward-only
+            if self.train_backend not in (None, "torch-autograd"):
+                raise _lib.VdmiError(f"guidance_variant.Unet3D trains through torch ops only (train_backend "
+                                     f"'torch-autograd'), not {self.train_backend!r}")
             from .autograd import guidance_variant_forward
             return guidance_variant_forward(self, x, time)
         return self.engine().forward(x, time)
