@@ -424,6 +424,15 @@ int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int cin, int cou
                     int nf, int h, int w, int ntaps, const int8_t* dy, const int8_t* dx, void* workspace,
                     vdmi_stream stream);
 
+/* Weight gradient of a 1x1 convolution / Linear layer straight from the channels-last rows (torch's weight gradient of
+ * to_qkv, to_out, res_conv: vdp.py:439, 541-543, 461-462), without the transposed copies:
+ *   dw[co][cin_off + ci] = sum over rows r of dy[r][co] * x[r][ci]          (written, not accumulated)
+ * x bf16 [rows][ldx], dy bf16 [rows][lddy]; cin, cout multiples of 8; dw float [cout][cin_total]; workspace:
+ * vdmi_rows_wgrad_workspace_bytes() bytes (partial tiles, added in a fixed order: results are repeatable). */
+size_t vdmi_rows_wgrad_workspace_bytes(int cin, int cout, int64_t rows);                   /* HOST */
+int vdmi_rows_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, int cin, int cout, int cin_total,
+                    int cin_off, int64_t rows, void* workspace, vdmi_stream stream);
+
 /* The same gradient for a (1,kh,kw) "same" convolution with few input channels (Unet3D.init_conv, vdp.py:644: 3 -> dim,
  * 7 x 7): a column of the contraction is a (ci, ky, kx) triple, so no lane idles on padding channels.  kh, kw odd;
  * dw float [cout][cin][kh][kw], written (not accumulated); workspace: vdmi_conv_wgrad_gather_workspace_bytes() bytes. */

@@ -168,6 +168,11 @@ def test_backward_entry_points_reject_bad_arguments():
     bad = (C.c_int8 * 9)(*[t[1] for t in taps])
     assert lib.vdmi_conv_wgrad(16, 16, 16, 64, 64, 64, 0, 10, 8, 8, 9, bad, dx, 16, None) == E_SHAPE  # not the 3 x 3 table
     assert lib.vdmi_conv_wgrad_gather(16, 16, 16, 3, 64, 10, 8, 8, 4, 4, 16, None) == E_SHAPE         # even kernel
+    assert lib.vdmi_rows_wgrad_workspace_bytes(64, 64, 1000) > 0
+    assert lib.vdmi_rows_wgrad_workspace_bytes(60, 64, 1000) == 0                                     # multiples of 8 only
+    assert lib.vdmi_rows_wgrad(None, 64, 16, 64, 16, 64, 64, 64, 0, 1000, 16, None) == E_ARG
+    assert lib.vdmi_rows_wgrad(16, 64, 16, 64, 16, 64, 64, 64, 8, 1000, 16, None) == E_SHAPE          # window past cin_total
+    assert lib.vdmi_rows_wgrad(16, 32, 16, 64, 16, 64, 64, 64, 0, 1000, 16, None) == E_SHAPE          # row pitch below cin
     assert lib.vdmi_rmsnorm_silu_bwd(None, 64, 16, 64, 16, 64, 1, 10, 64, None, None, None, 0, 8.0, None, None, None,
                                      None, None) == E_ARG
     assert lib.vdmi_rmsnorm_silu_bwd(16, 96, 16, 96, 16, 96, 1, 10, 96, 16, None, None, 0, 9.8, 16, None, None, None,

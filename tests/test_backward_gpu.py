@@ -535,3 +535,18 @@ def test_bf16_activation_stream_between_hip_layers():
     assert o_hip.dtype == torch.float32
     assert record("stream.focus.out", rel_err(o_hip, o_ref), 2e-2) < 2e-2
     assert record("stream.focus.param_grads", rel_err(g_hip, g_ref), 5e-2) < 5e-2
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(1000, 64, 64), (777, 72, 40), (64, 128, 384), (40000, 256, 768), (5, 8, 8)])
+def test_rows_wgrad_vs_torch(rows, cin, cout):
+    """vdmi_rows_wgrad (the weight gradient of a 1x1 convolution / Linear from the rows as they lie, through the transposing
+    LDS read) against dy^T x in float over the same bf16 operands; ragged row counts and channel widths."""
+    from tests.helpers import inp
+    from video_diffusion_amd import train_hip as T
+    x = inp("rw.x", (rows, cin)).to(DEV).to(torch.bfloat16)
+    dy = inp("rw.dy", (rows, cout)).to(DEV).to(torch.bfloat16)
+    dw = T.rows_wgrad(x, dy)
+    ref = dy.float().t() @ x.float()
+    assert dw.shape == (cout, cin)
+    assert record(f"rows_wgrad[{rows},{cin},{cout}]", rel_err(dw, ref), 1e-5) < 1e-5
+    assert torch.equal(dw, T.rows_wgrad(x, dy))           # fixed summation order: repeatable

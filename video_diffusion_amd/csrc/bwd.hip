@@ -176,6 +176,100 @@ __global__ __launch_bounds__(256) void wgrad1_kernel(const WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a 1x1 convolution / Linear straight from the channels-last rows (no transposed copy):
+//   dW[co][ci] = sum over rows r of dy[r][co] * x[r][ci]
+// The contraction index (the row) is the slow one in memory.  A workgroup copies 64 rows x 64 channels of each operand
+// into LDS as they lie (16-byte pieces, coalesced) and the waves read their MFMA fragments with the transposing LDS
+// read of gfx950 (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns and each lane receives one column's 4
+// values), two reads per operand and k-step.  LDS rows are 192 bytes apart: the 4 rows x 2 column blocks a 32-lane
+// half touches then fall into 64 different banks.  Stages are double buffered with the next stage's global loads in
+// flight during the current stage's MFMAs; one barrier per stage.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int RW_KC = 64;               // rows per stage
+constexpr int RW_PITCH = 192;           // bytes per LDS row (64 channels = 128 bytes, + 64)
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+
+struct RowsWgradArgs {
+    const __bf16* x;
+    const __bf16* dy;
+    float* part;                 // partial tiles [gridDim.z][tiles][64][64]
+    int ldx, lddy, cin, cout;
+    long long rows, per;         // rows in all, rows per blockIdx.z (a multiple of RW_KC)
+};
+
+__device__ __forceinline__ bf16x8 lds_tr_fragment(const char* base) {
+    // rows base .. base + 3 and base + 4 .. base + 7 of this lane's column: the 8 consecutive contraction values
+    typedef __attribute__((address_space(3))) s4v* lds_s4;
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base + 4 * RW_PITCH));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256) void wgrad_rows_kernel(const RowsWgradArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[2][2][RW_KC * RW_PITCH];      // [stage buffer][dy | x]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+    const long long r_begin = (long long)blockIdx.z * a.per;
+    const long long r_end = r_begin + a.per < a.rows ? r_begin + a.per : a.rows;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // staging: piece q = tid + 256 i of a tile is (row q >> 3, channels 8 (q & 7) ..)
+    const int prow = tid >> 3, pc = tid & 7;
+    const bool a_ok = co0 + pc * 8 < a.cout, b_ok = ci0 + pc * 8 < a.cin;
+    bf16x8 va[2], vb[2];
+    auto load = [&](long long r0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long r = r0 + prow + 32 * i;
+            va[i] = (a_ok && r < r_end) ? *reinterpret_cast<const bf16x8*>(a.dy + r * a.lddy + co0 + pc * 8) : zero8;
+            vb[i] = (b_ok && r < r_end) ? *reinterpret_cast<const bf16x8*>(a.x + r * a.ldx + ci0 + pc * 8) : zero8;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<bf16x8*>(&lds[buf][0][(prow + 32 * i) * RW_PITCH + pc * 16]) = va[i];
+            *reinterpret_cast<bf16x8*>(&lds[buf][1][(prow + 32 * i) * RW_PITCH + pc * 16]) = vb[i];
+        }
+    };
+    // fragment addresses: lane 4q + p of a 16-lane group g supplies row q, columns 4p .. 4p + 3 of the group's block;
+    // groups 0 / 1 are the operand's columns 0-15 / 16-31 at contraction values 0-7, groups 2 / 3 the same at 8-15
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int frag_row = 8 * (g >> 1) + q, frag_col = 16 * (g & 1) + 4 * pp;
+    const int a_off = frag_row * RW_PITCH + ((wave & 1) * 32 + frag_col) * 2;
+    const int b_off = frag_row * RW_PITCH + ((wave >> 1) * 32 + frag_col) * 2;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    int cur = 0;
+    if (r_begin < r_end) {
+        load(r_begin);
+        store(0);
+        __syncthreads();
+        for (long long r0 = r_begin; r0 < r_end; r0 += RW_KC) {
+            const bool more = r0 + RW_KC < r_end;
+            if (more) load(r0 + RW_KC);
+            const char* ta = &lds[cur][0][a_off];
+            const char* tb = &lds[cur][1][b_off];
+#pragma unroll
+            for (int ks = 0; ks < RW_KC / 16; ks += 2) {
+                const bf16x8 A0 = lds_tr_fragment(ta + ks * 16 * RW_PITCH), B0 = lds_tr_fragment(tb + ks * 16 * RW_PITCH);
+                const bf16x8 A1 = lds_tr_fragment(ta + (ks + 1) * 16 * RW_PITCH), B1 = lds_tr_fragment(tb + (ks + 1) * 16 * RW_PITCH);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc1, 0, 0, 0);
+            }
+            if (more) store(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    float* part = a.part + ((size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        part[((wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + (wave >> 1) * 32 + l31] = acc0[r] + acc1[r];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // wgrad of a (1,kh,kw) convolution with few input channels (init_conv: 3 -> dim, 7 x 7; torch's weight gradient,
 // vdp.py:644).  A tap-per-accumulator kernel would idle 29 of 32 columns, so here a column IS a (ci, ky, kx) triple:
 // n = (ci * kh + ky) * kw + kx, exactly the flattened weight index, and each lane gathers the fragment of its own
@@ -678,6 +772,52 @@ extern "C" int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int c
     const long long elems = (long long)p.tx * p.ty * ntaps * 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, part, (int)p.gz, p.tx,
                        p.ty, ntaps, dw, cout, cin, cin_total, cin_off);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+namespace {
+struct RowsWgradPlan { int tx, ty; long long per, gz; };
+int rows_wgrad_plan(int cin, int cout, int64_t rows, RowsWgradPlan* p) {
+    if (cin <= 0 || cout <= 0 || cin % 8 || cout % 8 || rows <= 0) return VDMI_E_SHAPE;
+    p->tx = (cout + 63) / 64;
+    p->ty = (cin + 63) / 64;
+    if (p->tx > 65535 || p->ty > 65535) return VDMI_E_SHAPE;
+    const long long tiles = (long long)p->tx * p->ty;
+    long long split = (768 + tiles - 1) / tiles;          // ~3 workgroups per CU (48 KB of LDS each)
+    const long long stages = (rows + RW_KC - 1) / RW_KC;
+    if (split > stages) split = stages;
+    p->per = (stages + split - 1) / split * RW_KC;
+    p->gz = (rows + p->per - 1) / p->per;
+    return p->gz > 65535 ? VDMI_E_SHAPE : VDMI_OK;
+}
+}   // namespace
+
+extern "C" size_t vdmi_rows_wgrad_workspace_bytes(int cin, int cout, int64_t rows) {
+    RowsWgradPlan p;
+    if (rows_wgrad_plan(cin, cout, rows, &p) != VDMI_OK) return 0;
+    return (size_t)p.gz * p.tx * p.ty * 4096 * sizeof(float);
+}
+
+extern "C" int vdmi_rows_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, int cin, int cout,
+                               int cin_total, int cin_off, int64_t rows, void* workspace, vdmi_stream stream) {
+    if (!x || !dy || !dw || !workspace) return VDMI_E_ARG;
+    if (cin_off < 0 || cin_off + cin > cin_total || ldx < cin || lddy < cout || ldx % 8 || lddy % 8) return VDMI_E_SHAPE;
+    RowsWgradPlan p;
+    const int st = rows_wgrad_plan(cin, cout, rows, &p);
+    if (st != VDMI_OK) return st;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return VDMI_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RowsWgradArgs a;
+    a.x = static_cast<const __bf16*>(x); a.ldx = ldx;
+    a.dy = static_cast<const __bf16*>(dy); a.lddy = lddy;
+    a.part = static_cast<float*>(workspace);
+    a.cin = cin; a.cout = cout; a.rows = rows; a.per = p.per;
+    hipLaunchKernelGGL(wgrad_rows_kernel, dim3((unsigned)p.tx, (unsigned)p.ty, (unsigned)p.gz), dim3(256), 0, s, a);
+    VDMI_LAUNCH_CHECK();
+    const long long elems = (long long)p.tx * p.ty * 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, a.part, (int)p.gz, p.tx,
+                       p.ty, 1, dw, cout, cin, cin_total, cin_off);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }

@@ -157,6 +157,20 @@ def conv_wgrad(x_t: torch.Tensor, dy_t: torch.Tensor, cin: int, cout: int, nf: i
     return dw
 
 
+def rows_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """float32 [cout][cin] weight gradient of a 1x1 convolution / Linear from its input rows x [rows][cin] and output-gradient
+    rows dy [rows][cout] (bf16, channels-last) - no transposed copies."""
+    rows, cin = x.shape
+    cout = dy.shape[1]
+    assert dy.shape[0] == rows and x.is_contiguous() and dy.is_contiguous()
+    lib = _lib.lib()
+    dw = torch.empty(cout, cin, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.vdmi_rows_wgrad_workspace_bytes(cin, cout, rows), device=x.device, dtype=torch.uint8)
+    check(lib.vdmi_rows_wgrad(x.data_ptr(), cin, dy.data_ptr(), cout, dw.data_ptr(), cin, cout, cin, 0, rows, ws.data_ptr(),
+                              _stream()), "vdmi_rows_wgrad")
+    return dw
+
+
 def conv_wgrad_gather(x_t, dy_t, cin, cout, nf, h, w, kh, kw) -> torch.Tensor:
     """float32 (cout, cin, 1, kh, kw) weight gradient of a small-cin convolution (init_conv)."""
     lib = _lib.lib()
@@ -249,7 +263,7 @@ class ResnetBlockFn(torch.autograd.Function):
         dh1 = conv_rows(dy2, DevPack(w2, True), None, frames, f, h, w)
         # block1
         dy1, dg1, db1, dscale, dshift = rmsnorm_silu_bwd_rows(y1, dh1, g1v, scale_c, shift_c, b, f * hw)
-        x_t = rows_transposed(xr, frames, hw) if (need[3] or (wres is not None and need[9])) else None
+        x_t = rows_transposed(xr, frames, hw) if need[3] else None
         dw1 = conv_wgrad(x_t, rows_transposed(dy1, frames, hw), cin, cout, frames, h, w, 9) if need[3] else None
         # residual branch, then the input gradient: dgrad of conv1 + (res_conv's dgrad | the identity)
         if not ctx.with_res:
@@ -258,7 +272,7 @@ class ResnetBlockFn(torch.autograd.Function):
             dwres = dbres = None
             dx_res = do
         else:
-            dwres = conv_wgrad(x_t, rows_transposed(do, frames, hw), cin, cout, frames, h, w, 1) if need[9] else None
+            dwres = rows_wgrad(xr, do).view(cout, cin, 1, 1, 1) if need[9] else None
             dbres = colsum_rows(do) if need[10] else None
             dx_res = conv_rows(do, DevPack(wres, True), None, frames, f, h, w)
         dx = conv_rows(dy1, DevPack(w1, True), None, frames, f, h, w, residual=dx_res)
@@ -439,8 +453,7 @@ class TemporalAttnFn(torch.autograd.Function):
         do = conv_rows(dyr, _linear_pack(wout.detach().contiguous(), True), None, frames, f, h, w)
         dwout = None
         if need[3]:
-            dwout = conv_wgrad(rows_transposed(o, frames, hw), rows_transposed(dyr, frames, hw), hid, c, frames, h, w,
-                               1).reshape(c, hid)
+            dwout = rows_wgrad(o, dyr)
         # attention core
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias_c) if (bias_c is not None and need[4]) else None
@@ -451,8 +464,7 @@ class TemporalAttnFn(torch.autograd.Function):
         dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
         dwqkv = dgamma = None
         if need[1] or need[2]:
-            dwp = conv_wgrad(rows_transposed(xh, frames, hw), rows_transposed(dqkv, frames, hw), c, 3 * hid, frames, h, w,
-                             1).reshape(3 * hid, c)
+            dwp = rows_wgrad(xh, dqkv)
             dwqkv = dwp * gamma.detach().reshape(1, c)
             dgamma = (dwp * wqkv.detach()).sum(0).reshape(gamma.shape)
         dx = torch.empty_like(xr)
@@ -559,13 +571,15 @@ def strided_wgrad(big: torch.Tensor, small: torch.Tensor, frames: int, h: int, w
     bp = F.pad(big.view(frames, h, w, cb), (0, 0, 1, 1, 1, 1))                      # zero border of one pixel
     s2d = bp.view(frames, oh + 1, 2, ow + 1, 2, cb).permute(0, 1, 3, 2, 4, 5).reshape(frames * (oh + 1) * (ow + 1), 4 * cb)
     sp = F.pad(small.view(frames, oh, ow, cs), (0, 0, 0, 1, 0, 1)).reshape(frames * (oh + 1) * (ow + 1), cs)
-    hw2 = (oh + 1) * (ow + 1)
-    big_t = rows_transposed(s2d.contiguous(), frames, hw2)
-    small_t = rows_transposed(sp.contiguous(), frames, hw2)
+    # `small` is zero in its padding row and column, so a tap (ty, tx) is a plain shift of the flattened rows: where the
+    # shifted row wraps into the next image row or frame, the other factor is zero
+    s2d, sp = s2d.contiguous(), sp.contiguous()
+    total = s2d.shape[0]
     dw = torch.empty(cs, cb, 4, 4, device=big.device, dtype=torch.float32)
     for ty in (0, 1):
         for tx in (0, 1):
-            d2 = conv_wgrad(big_t, small_t, 4 * cb, cs, frames, oh + 1, ow + 1, 1, tap=(ty, tx)).view(cs, 2, 2, cb)
+            shift = ty * (ow + 1) + tx
+            d2 = rows_wgrad(s2d[shift:], sp[:total - shift]).view(cs, 2, 2, cb)
             for a in (0, 1):
                 for b in (0, 1):
                     dw[:, :, 2 * ty + a, 2 * tx + b] = d2[:, a, b]
@@ -689,8 +703,7 @@ class SlaFn(torch.autograd.Function):
         do = conv_rows(dyr, _linear_pack(wo2, True), None, frames, f, h, w)
         dwout = None
         if need[3]:
-            dwout = conv_wgrad(rows_transposed(out, frames, n), rows_transposed(dyr, frames, n), hid, c, frames, h, w,
-                               1).reshape(wout.shape)
+            dwout = rows_wgrad(out, dyr).reshape(wout.shape)
         p_dctx = _sla_reduce(qt.data_ptr(), hid, do.data_ptr(), hid, p_ctx, frames, n, heads, 1, dy.device)
         dqkv = torch.empty_like(qkv)
         check(lib.vdmi_sla_train_rows_bwd(qkv.data_ptr(), qt.data_ptr(), do.data_ptr(), p_ctx.data_ptr(), p_dctx.data_ptr(),
@@ -698,8 +711,7 @@ class SlaFn(torch.autograd.Function):
         dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
         dwqkv = dgamma = None
         if need[1] or need[2]:
-            dwp = conv_wgrad(rows_transposed(xh, frames, n), rows_transposed(dqkv, frames, n), c, 3 * hid, frames, h, w,
-                             1).reshape(3 * hid, c)
+            dwp = rows_wgrad(xh, dqkv)
             dwqkv = (dwp * gamma.detach().reshape(1, c)).reshape(wqkv.shape)
             dgamma = (dwp * wqkv.detach().reshape(3 * hid, c)).sum(0).reshape(gamma.shape)
         dx = torch.empty_like(xr)
