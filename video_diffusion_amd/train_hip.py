@@ -340,8 +340,7 @@ class PointwiseConvFn(torch.autograd.Function):
         cpad = (cout + 7) // 8 * 8
         dr = torch.zeros(b * f * h * w, cpad, device=x.device, dtype=torch.bfloat16)
         dr[:, :cout] = dout.permute(0, 2, 3, 4, 1).reshape(-1, cout)
-        dw = conv_wgrad(rows_transposed(to_rows(x), b * f, h * w), rows_transposed(dr, b * f, h * w), cin, cout, b * f,
-                        h, w, 1)
+        dw = rows_wgrad(to_rows(x), dr)[:cout].reshape(cout, cin, 1, 1, 1).contiguous()
         return dx, dw, dout.sum(dim=(0, 2, 3, 4))
 
 
