@@ -550,3 +550,34 @@ def test_rows_wgrad_vs_torch(rows, cin, cout):
     assert dw.shape == (cout, cin)
     assert record(f"rows_wgrad[{rows},{cin},{cout}]", rel_err(dw, ref), 1e-5) < 1e-5
     assert torch.equal(dw, T.rows_wgrad(x, dy))           # fixed summation order: repeatable
+
+
+def test_long_token_axis_attention_matches_the_explicit_softmax():
+    """autograd._attention over 1024 or more tokens without bias or mask (SpatioTemporalAttention,
+    version1diffusion.py:325-345) goes through torch's fused attention op: same output and gradients as the explicit
+    softmax(q k^T) v (taken here by passing an all-zero bias), in float and with the "hip" backend's bf16 operands."""
+    from tests.helpers import inp
+    from video_diffusion_amd import autograd as A
+    from video_diffusion_amd.version1 import SpatioTemporalAttention
+    att = SpatioTemporalAttention(64, heads=4).to(DEV)
+    n = 1280
+    x = inp("sdpa.x", (2, 1, n, 64)).to(DEV)
+    zero_bias = torch.zeros(n, n, device=DEV)
+
+    def run(bias, hip):
+        A._HIP_ATTN = hip
+        try:
+            xr = x.clone().requires_grad_(True)
+            out = A._attention(att, xr, bias)
+            g, = torch.autograd.grad(out.square().mean(), xr)
+        finally:
+            A._HIP_ATTN = False
+        return out.detach(), g
+
+    o_ref, g_ref = run(zero_bias, False)
+    o_f, g_f = run(None, False)
+    assert record("sdpa.float.out", rel_err(o_f, o_ref), 1e-4) < 1e-4
+    assert record("sdpa.float.grad", rel_err(g_f, g_ref), 1e-4) < 1e-4
+    o_b, g_b = run(None, True)
+    assert record("sdpa.bf16.out", rel_err(o_b, o_ref), 1e-2) < 1e-2
+    assert record("sdpa.bf16.grad", rel_err(g_b, g_ref), 2e-2) < 2e-2

@@ -12,6 +12,8 @@ Workloads (random-init weights, synthetic inputs):
   textcfg    Unet3D(dim=128, dim_mults=(1,2,4,8), channels=3, cond_dim=768) on (--cfg-batch, 3, 16, 64, 64) with
              classifier-free guidance cond_scale=2: one step = one pass over the doubled batch (rows B.. take the
              null embedding) + guidance + posterior step, replayed as a HIP graph; with its roofline block.
+  guidance   (on request) version1.Unet3D(dim=64, channels=4) on latents (--guid-batch, 4, F, --guid-latent, ..): the
+             reconstruction-guidance gradient and the guided step, denoiser gradient on the HIP kernels vs torch ops.
   train      Unet3D(dim=128, dim_mults=(1,2,4,8), channels=3) on (--train-batch, 3, 16, 128, 128): one p_losses
              forward + backward (L1 loss on the predicted noise), with the all-torch backend ("torch-autograd", fp32 and
              under bf16 autocast) and with the ResnetBlocks forward + backward on the HIP kernels ("hip-resnet").
@@ -168,8 +170,42 @@ def train_step(args, dev):
     print(json.dumps(out), flush=True)
 
 
+def guidance_step(args, dev):
+    """One guided sampling step of the version1 variant (version1diffusion.py:572-592, 707-747): the reconstruction-guidance
+    gradient (forward + input gradient through the denoiser and the VAE decoder) and the denoising step after it, with the
+    denoiser's gradient on the HIP training kernels and on torch ops."""
+    from video_diffusion_amd import VAE, train_hip, version1 as V1
+    torch.manual_seed(0)
+    B, F, S, ov = args.guid_batch, args.frames, args.guid_latent, 2
+    unet = V1.Unet3D(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
+    vae = VAE(channels=3, latent_dim=4, base_dim=64)
+    gd = V1.GaussianDiffusion(unet.eval(), vae.eval(), image_size=8 * S, num_frames=F, channels=3, timesteps=1000).to(dev)
+    z = torch.randn(B, 4, F, S, S, device=dev)
+    t = torch.full((B,), 500, device=dev, dtype=torch.long)
+    prev = torch.rand(B, 3, ov, 8 * S, 8 * S, device=dev)
+    fn = V1.temporal_consistency_guidance(gd, prev, ov, w_r=1.0)
+    out = {"workload": f"guided sampling step: version1.Unet3D(dim=64, channels=4) on latents {tuple(z.shape)}, reconstruction "
+                       f"guidance over {ov} overlap frames decoded to {8 * S}x{8 * S}, random-init weights",
+           "supports_hip": bool(train_hip.supports(gd.denoise_fn)), "ms": {}}
+    orig = train_hip.supports
+    for name, forced in (("guidance gradient, denoiser on the HIP training kernels", None),
+                         ("guidance gradient, denoiser as torch ops", lambda m: False)):
+        train_hip.supports = forced or orig
+        try:
+            out["ms"][name] = round(timed(lambda: fn(z, t), args.steps, warmup=2), 2)
+            out["ms"][name.replace("guidance gradient", "guided p_sample")] = round(
+                timed(lambda: gd.p_sample(z, t, guidance_fn=fn, guidance_scale=1.0), args.steps, warmup=2), 2)
+        finally:
+            train_hip.supports = orig
+    with torch.no_grad():
+        out["ms"]["p_sample without guidance"] = round(timed(lambda: gd.p_sample(z, t), args.steps, warmup=2), 2)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--guid-batch", type=int, default=2)
+    ap.add_argument("--guid-latent", type=int, default=32)
     ap.add_argument("--train-batch", type=int, default=1)
     ap.add_argument("--train-size", type=int, default=128)
     ap.add_argument("--train-dim", type=int, default=128)
@@ -200,6 +236,8 @@ def main():
         text_cfg(args, dev)
     if "train" in only:        # only on request: the all-torch backends take seconds per step
         train_step(args, dev)
+    if "guidance" in only:
+        guidance_step(args, dev)
     if not (want("framecond") or want("vae")):
         return
 

@@ -84,6 +84,14 @@ def _attention(att, x, pos_bias=None, focus=None):
     q = q * att.scale
     if getattr(att, "rotary_emb", None) is not None:
         q, k = _rotate(q, att.rotary_emb), _rotate(k, att.rotary_emb)
+    if pos_bias is None and focus is None and x.is_cuda and n >= 1024:
+        # long token axes (SpatioTemporalAttention over all f*h*w positions, version1diffusion.py:325-345): torch's fused
+        # attention op, which never materialises the n x n matrices (q is already scaled)
+        q4, k4, v4 = (t.reshape(b * g, heads, n, -1) for t in (q, k, v))       # the fused kernels take 4-D operands
+        if _HIP_ATTN:       # the "hip" backend's arithmetic: bf16 q, k, v rows, float accumulation (as its HIP attention cores)
+            q4, k4, v4 = q4.to(torch.bfloat16), k4.to(torch.bfloat16), v4.to(torch.bfloat16)
+        out = F.scaled_dot_product_attention(q4, k4, v4, scale=1.0).to(q.dtype).reshape(b, g, heads, n, -1)
+        return att.to_out(out.transpose(2, 3).reshape(b, g, n, -1))
     sim = q @ k.transpose(-1, -2)
     if pos_bias is not None:
         sim = sim + pos_bias

@@ -169,17 +169,24 @@ def temporal_consistency_guidance(model, prev_frames, overlap_frames, w_r=1.0):
         fn = model.denoise_fn
         z = z_t.detach().clone().requires_grad_(True)
         backend = getattr(fn, "train_backend", None)
+        # only d/dz_t is wanted: with the parameters frozen for the duration no layer computes a weight gradient
+        # (autograd asks a Function for every input that requires grad, whatever the caller differentiates)
+        frozen = [p for p in fn.parameters() if p.requires_grad]
         with torch.enable_grad():
-            if hasattr(fn, "train_backend"):
-                from . import train_hip
-                fn.train_backend = "hip" if (z.is_cuda and train_hip.supports(fn)) else "torch-autograd"
             try:
+                for p in frozen:
+                    p.requires_grad_(False)
+                if hasattr(fn, "train_backend"):
+                    from . import train_hip
+                    fn.train_backend = "hip" if (z.is_cuda and train_hip.supports(fn)) else "torch-autograd"
                 x_recon = model.predict_start_from_noise(z, t, fn(z, t))
                 overlap = x_recon[:, :, :overlap_frames] if x_recon.dim() == 5 else x_recon
                 pixels = (model.vae.decode(overlap / model.latent_scale).clamp(-1, 1) + 1) / 2
                 loss = nn.functional.mse_loss(pixels, prev_frames, reduction='mean')
                 grad = torch.autograd.grad(loss, z)[0]
             finally:
+                for p in frozen:
+                    p.requires_grad_(True)
                 if hasattr(fn, "train_backend"):
                     fn.train_backend = backend
         return (-w_r * extract(model.alphas_cumprod, t, z_t.shape) * grad).detach()
