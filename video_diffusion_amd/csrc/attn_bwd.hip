@@ -160,6 +160,25 @@ __device__ __forceinline__ float lds_dot32(const float* p, const float (&v)[32])
     }
     return s0 + s1;
 }
+// a row read once into registers for a dot product AND an update (the LDS atomics of the bias gradient sit between the two
+// uses and keep the compiler from merging two reads of the same row)
+__device__ __forceinline__ void lds_load32(const float* p, float (&r)[32]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * k);
+        r[4 * k] = a[0]; r[4 * k + 1] = a[1]; r[4 * k + 2] = a[2]; r[4 * k + 3] = a[3];
+    }
+}
+__device__ __forceinline__ float dot32(const float (&r)[32], const float (&v)[32]) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k += 2) { s0 += r[k] * v[k]; s1 += r[k + 1] * v[k + 1]; }
+    return s0 + s1;
+}
+__device__ __forceinline__ void axpy32(const float (&r)[32], float w, float (&acc)[32]) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] += w * r[k];
+}
 __device__ __forceinline__ void lds_axpy32(const float* p, float w, float (&acc)[32]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -263,10 +282,12 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
                 for (int d = 0; d < 32; ++d) dq[d] = 0.f;
                 for (int j = 0; j < F; ++j) {
                     const int sj = ((s * F + j) * HP + hl) * CORE_ROWF;
-                    const float sc = lds_dot32(Kl + sj, q) + (bias_i ? bias_i[j] : 0.f);
+                    float kr[32];
+                    lds_load32(Kl + sj, kr);
+                    const float sc = dot32(kr, q) + (bias_i ? bias_i[j] : 0.f);
                     const float p = __expf(sc - lse);
                     const float ds = p * (lds_dot32(Vl + sj, g) - D);
-                    lds_axpy32(Kl + sj, ds, dq);
+                    axpy32(kr, ds, dq);
                     if (a.dbias) atomicAdd(&Bl[(h * F + i) * F + j], ds);
                 }
 #pragma unroll
@@ -280,11 +301,14 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
                 for (int qi = 0; qi < F; ++qi) {
                     const int slq = (s * F + qi) * HP + hl, sq = slq * CORE_ROWF;
                     const float bq = a.bias ? a.bias[((long long)h * F + qi) * F + i] : 0.f;
-                    const float sc = lds_dot32(Ql + sq, k) + bq;
+                    float qr[32], gr[32];
+                    lds_load32(Ql + sq, qr);
+                    lds_load32(Gl + sq, gr);
+                    const float sc = dot32(qr, k) + bq;
                     const float p = __expf(sc - Sl[2 * slq]);
-                    const float ds = p * (lds_dot32(Gl + sq, v) - Sl[2 * slq + 1]);
-                    lds_axpy32(Ql + sq, ds, dk);
-                    lds_axpy32(Gl + sq, p, dv);
+                    const float ds = p * (dot32(gr, v) - Sl[2 * slq + 1]);
+                    axpy32(qr, ds, dk);
+                    axpy32(gr, p, dv);
                 }
                 rotate32(dk, rc, rs, true);
                 store32(a.out + row * ld + (H + h) * 32, dk);
