@@ -522,7 +522,7 @@ struct NormBwdArgs {
 };
 
 __global__ __launch_bounds__(256) void rmsnorm_silu_bwd_kernel(const NormBwdArgs a) {
-    __shared__ float colred[4 * 2048];
+    extern __shared__ float colred[];                // [4][c]: the four per-channel sums of this workgroup
     __shared__ float red1[4], red2[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int LP = a.c / 8, R = 256 / LP;            // threads per row, rows per pass
@@ -561,17 +561,26 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_bwd_kernel(const NormBwdArgs
     const long long r_begin = (long long)blockIdx.x * a.rows_per_chunk;
     const long long r_end = r_begin + a.rows_per_chunk < a.rows_per_batch ? r_begin + a.rows_per_chunk : a.rows_per_batch;
     const long long passes = (a.rows_per_chunk + R - 1) / R;
+    // the rows of pass it + 1 are requested before pass it computes: a pass is a dependent load - reduce - reduce - store
+    // chain, and this keeps two rows per thread in flight
+    auto row_of = [&](long long it) -> long long {
+        const long long rl = r_begin + it * R + rslot;
+        return (long long)b * a.rows_per_batch + (rl < r_end ? rl : r_begin);
+    };
+    bf16x8 y8 = *reinterpret_cast<const bf16x8*>(a.y + row_of(0) * a.ldy + ch);
+    bf16x8 d8 = *reinterpret_cast<const bf16x8*>(a.dh + row_of(0) * a.ldh + ch);
     for (long long it = 0; it < passes; ++it) {
         const long long rl = r_begin + it * R + rslot;
         const bool valid = rl < r_end;
-        const long long row = (long long)b * a.rows_per_batch + (valid ? rl : r_begin);
+        const long long row = row_of(it);
         if (LP > 64) __syncthreads();                // red1 / red2 of the previous pass have been read
         float yv[8], dhv[8];
-        {
-            const bf16x8 y8 = *reinterpret_cast<const bf16x8*>(a.y + row * a.ldy + ch);
-            const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(a.dh + row * a.ldh + ch);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { yv[e] = (float)y8[e]; dhv[e] = valid ? (float)d8[e] : 0.f; }
+        for (int e = 0; e < 8; ++e) { yv[e] = (float)y8[e]; dhv[e] = valid ? (float)d8[e] : 0.f; }
+        if (it + 1 < passes) {
+            const long long rn = row_of(it + 1);
+            y8 = *reinterpret_cast<const bf16x8*>(a.y + rn * a.ldy + ch);
+            d8 = *reinterpret_cast<const bf16x8*>(a.dh + rn * a.ldh + ch);
         }
         float ss = 0.f;
 #pragma unroll
@@ -879,8 +888,8 @@ extern "C" int vdmi_rmsnorm_silu_bwd(const void* y, int ldy, const void* dh, int
     long long chunks = (rows_per_batch + per - 1) / per;
     if (chunks > 0x7fffffffLL) return VDMI_E_SHAPE;
     a.rows_per_chunk = per;
-    hipLaunchKernelGGL(rmsnorm_silu_bwd_kernel, dim3((unsigned)chunks, (unsigned)batch), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(rmsnorm_silu_bwd_kernel, dim3((unsigned)chunks, (unsigned)batch), dim3(256),
+                       (size_t)4 * c * sizeof(float), static_cast<hipStream_t>(stream), a);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
