@@ -425,7 +425,7 @@ int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int cin, int cou
                     vdmi_stream stream);
 
 /* Weight gradient of a 1x1 convolution / Linear layer straight from the channels-last rows (torch's weight gradient of
- * to_qkv, to_out, res_conv: vdp.py:439, 541-543, 461-462), without the transposed copies:
+ * to_qkv, to_out, res_conv: vdp.py:439, 460-461, 560-561), without the transposed copies:
  *   dw[co][cin_off + ci] = sum over rows r of dy[r][co] * x[r][ci]          (written, not accumulated)
  * x bf16 [rows][ldx], dy bf16 [rows][lddy]; cin, cout multiples of 8; dw float [cout][cin_total]; workspace:
  * vdmi_rows_wgrad_workspace_bytes() bytes (partial tiles, added in a fixed order: results are repeatable). */
