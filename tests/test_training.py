@@ -236,6 +236,11 @@ def test_trainer_hip_resnet_backend_follows_torch_backend(tmp_path):
         for i, (a, b) in enumerate(zip(hip, ref)):
             assert record(f"trainer_{backend}.loss_step{i}", abs(a - b) / abs(b), 3e-2) < 3e-2
         assert tr.model.denoise_fn.train_backend == backend
+    # "auto" resolves to the HIP layers for this model (every width a power of two from 64) ...
+    auto, tr = run("auto", str(tmp_path / "r_auto"))
+    assert tr.model.denoise_fn.train_backend == "hip" and tr.opt.defaults.get("fused")
+    for i, (a, b) in enumerate(zip(auto, ref)):
+        assert record(f"trainer_auto.loss_step{i}", abs(a - b) / abs(b), 3e-2) < 3e-2
     # Trainer(amp=True): the torch layers run under autocast with a gradient scaler, the HIP layers take the scaled
     # gradients in bf16 (fp32's exponent range); the loss follows the full-precision run
     amp_losses, _ = run("hip", str(tmp_path / "r_amp"), amp=True)
