@@ -581,3 +581,21 @@ def test_long_token_axis_attention_matches_the_explicit_softmax():
     o_b, g_b = run(None, True)
     assert record("sdpa.bf16.out", rel_err(o_b, o_ref), 1e-2) < 1e-2
     assert record("sdpa.bf16.grad", rel_err(g_b, g_ref), 2e-2) < 2e-2
+
+
+def test_fixed_weights_store_follows_the_version_counter():
+    """train_hip.fixed_weights: a parameter's packed set is found again while tensor, version counter and pointer are the
+    same, and rebuilt after an in-place update (what an optimizer step or load_state_dict does)."""
+    from video_diffusion_amd import train_hip as T
+    w = torch.nn.Parameter(torch.randn(64, 64, 1, 3, 3, device=DEV))
+    store = {}
+    with T.fixed_weights(store):
+        p0 = T.param_pack(w, False)
+        assert T.param_pack(w, False) is p0 and T.param_pack(w, True) is not p0 and len(store) == 2
+        with torch.no_grad():
+            w.mul_(2.0)
+        p1 = T.param_pack(w, False)
+        assert p1 is not p0
+        assert torch.equal(p1.data.float(), (p0.data.float() * 2.0))
+    assert T._PACKS is None
+    assert T.param_pack(w, False) is not p1                 # outside a block nothing is kept

@@ -98,6 +98,42 @@ class DevPack:
         self._keep = w3
 
 
+_PACKS = None        # {(id, version, pointer, transposed): DevPack} while a caller has declared the weights fixed
+
+
+class fixed_weights:
+    """`with fixed_weights(store):` - the caller guarantees that the parameters keep their values between the forwards and
+    backwards run inside this and later blocks with the same `store` (a dict it owns): the packed weight sets of the
+    ResnetBlocks are then built once and found again by (tensor, version counter, pointer).  The guided sampler uses it
+    (weights are frozen while it samples); training does not - an optimizer step changes every weight anyway."""
+
+    def __init__(self, store: dict):
+        self.store = store
+
+    def __enter__(self):
+        global _PACKS
+        self.prev, _PACKS = _PACKS, self.store
+        return self
+
+    def __exit__(self, *exc):
+        global _PACKS
+        _PACKS = self.prev
+        return False
+
+
+def param_pack(weight: torch.Tensor, transposed: bool) -> DevPack:
+    """DevPack of a parameter, through the store of an enclosing fixed_weights block when there is one."""
+    if _PACKS is None:
+        return DevPack(weight, transposed)
+    key = (id(weight), weight._version, weight.data_ptr(), transposed)
+    hit = _PACKS.get(key)
+    if hit is None or hit[0]() is not weight:
+        import weakref
+        hit = (weakref.ref(weight), DevPack(weight, transposed))
+        _PACKS[key] = hit
+    return hit[1]
+
+
 def conv_rows(src: torch.Tensor, pack: DevPack, bias, frames: int, fpb: int, h: int, w: int, residual=None) -> torch.Tensor:
     """Stride-1 'same' convolution of channels-last rows through vdmi_tapgemm (PLAIN epilogue, + bias, + residual rows)."""
     assert src.shape[1] == pack.k and src.dtype == torch.bfloat16 and src.is_contiguous()
@@ -228,9 +264,9 @@ class ResnetBlockFn(torch.autograd.Function):
         else:
             scale_c = shift_c = None
             gain1, bstride = g1v, 0
-        y1 = conv_rows(xr, DevPack(w1, False), b1.detach().float().contiguous(), frames, f, h, w)
+        y1 = conv_rows(xr, param_pack(w1, False), b1.detach().float().contiguous(), frames, f, h, w)
         h1 = rmsnorm_silu_rows(y1, gain1, shift_c, bstride, f * hw)
-        y2 = conv_rows(h1, DevPack(w2, False), b2.detach().float().contiguous(), frames, f, h, w)
+        y2 = conv_rows(h1, param_pack(w2, False), b2.detach().float().contiguous(), frames, f, h, w)
         if not with_res:
             wres = None
             out = rmsnorm_silu_rows(y2, g2v, None, 0, f * hw)
@@ -238,7 +274,7 @@ class ResnetBlockFn(torch.autograd.Function):
             out = rmsnorm_silu_rows(y2, g2v, None, 0, f * hw, residual=xr)
         else:
             h2 = rmsnorm_silu_rows(y2, g2v, None, 0, f * hw)
-            out = conv_rows(xr, DevPack(wres, False), bres.detach().float().contiguous(), frames, f, h, w, residual=h2)
+            out = conv_rows(xr, param_pack(wres, False), bres.detach().float().contiguous(), frames, f, h, w, residual=h2)
         ctx.save_for_backward(xr, y1, h1, y2, g1v, g2v, scale_c, shift_c, w1, w2, wres)
         ctx.dims = (b, cin, cout, f, h, w)
         ctx.with_res = with_res
@@ -260,7 +296,7 @@ class ResnetBlockFn(torch.autograd.Function):
         dw2 = None
         if need[6]:
             dw2 = conv_wgrad(rows_transposed(h1, frames, hw), rows_transposed(dy2, frames, hw), cout, cout, frames, h, w, 9)
-        dh1 = conv_rows(dy2, DevPack(w2, True), None, frames, f, h, w)
+        dh1 = conv_rows(dy2, param_pack(w2, True), None, frames, f, h, w)
         # block1
         dy1, dg1, db1, dscale, dshift = rmsnorm_silu_bwd_rows(y1, dh1, g1v, scale_c, shift_c, b, f * hw)
         x_t = rows_transposed(xr, frames, hw) if need[3] else None
@@ -274,8 +310,8 @@ class ResnetBlockFn(torch.autograd.Function):
         else:
             dwres = rows_wgrad(xr, do).view(cout, cin, 1, 1, 1) if need[9] else None
             dbres = colsum_rows(do) if need[10] else None
-            dx_res = conv_rows(do, DevPack(wres, True), None, frames, f, h, w)
-        dx = conv_rows(dy1, DevPack(w1, True), None, frames, f, h, w, residual=dx_res)
+            dx_res = conv_rows(do, param_pack(wres, True), None, frames, f, h, w)
+        dx = conv_rows(dy1, param_pack(w1, True), None, frames, f, h, w, residual=dx_res)
         return (from_rows(dx, b, f, h, w, ctx.act), dscale, dshift, dw1, db1, dg1.view(cout, 1, 1, 1), dw2, db2,
                 dg2.view(cout, 1, 1, 1), dwres, dbres, None)
 

@@ -163,6 +163,8 @@ def temporal_consistency_guidance(model, prev_frames, overlap_frames, w_r=1.0):
     for param in model.vae.decoder.parameters():
         param.requires_grad = False
 
+    packs = {}       # packed weight sets of the HIP training layers, kept over the steps of the loop (weights are frozen)
+
     def guidance_fn(z_t, t):
         if prev_frames is None:
             return torch.zeros_like(z_t)
@@ -179,11 +181,13 @@ def temporal_consistency_guidance(model, prev_frames, overlap_frames, w_r=1.0):
                 if hasattr(fn, "train_backend"):
                     from . import train_hip
                     fn.train_backend = "hip" if (z.is_cuda and train_hip.supports(fn)) else "torch-autograd"
-                x_recon = model.predict_start_from_noise(z, t, fn(z, t))
-                overlap = x_recon[:, :, :overlap_frames] if x_recon.dim() == 5 else x_recon
-                pixels = (model.vae.decode(overlap / model.latent_scale).clamp(-1, 1) + 1) / 2
-                loss = nn.functional.mse_loss(pixels, prev_frames, reduction='mean')
-                grad = torch.autograd.grad(loss, z)[0]
+                from . import train_hip as _th
+                with _th.fixed_weights(packs):
+                    x_recon = model.predict_start_from_noise(z, t, fn(z, t))
+                    overlap = x_recon[:, :, :overlap_frames] if x_recon.dim() == 5 else x_recon
+                    pixels = (model.vae.decode(overlap / model.latent_scale).clamp(-1, 1) + 1) / 2
+                    loss = nn.functional.mse_loss(pixels, prev_frames, reduction='mean')
+                    grad = torch.autograd.grad(loss, z)[0]
             finally:
                 for p in frozen:
                     p.requires_grad_(True)
