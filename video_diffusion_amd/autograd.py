@@ -120,8 +120,14 @@ def _rot_tables(rot, nf, device):
         return None
     if getattr(rot, "convention", "half") != "half":
         raise NotImplementedError("the HIP temporal attention backward takes the half-split rotary convention")
-    ang = torch.arange(nf, device=device, dtype=torch.float32)[:, None] * rot.inv_freq.to(device).float()[None, :]
-    return ang.cos().contiguous(), ang.sin().contiguous()
+    # one table per (frame count, device) and state of the frequencies: every temporal layer of a forward shares the module
+    key = (nf, str(device), rot.inv_freq.data_ptr(), rot.inv_freq._version, torch.is_inference_mode_enabled())
+    hit = getattr(rot, "_vdmi_tables", None)
+    if hit is None or hit[0] != key:
+        ang = torch.arange(nf, device=device, dtype=torch.float32)[:, None] * rot.inv_freq.to(device).float()[None, :]
+        hit = (key, (ang.cos().contiguous(), ang.sin().contiguous()))
+        object.__setattr__(rot, "_vdmi_tables", hit)
+    return hit[1]
 
 
 def _temporal(res, x, pos_bias, focus=None):
