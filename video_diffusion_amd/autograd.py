@@ -216,11 +216,15 @@ def _cross_attention_ops(res, x, ctx):
 def _pos_bias(unet, nf, device):
     # vdp.py:274-312: integer buckets from the library's host routine, gathered from the LIVE embedding weight
     rpb = unet.time_rel_pos_bias
-    buckets = np.empty((nf, nf), dtype=np.int32)
-    _lib.check(_lib.lib().vdmi_relpos_buckets(nf, rpb.num_buckets, rpb.max_distance, buckets.ctypes.data),
-               "vdmi_relpos_buckets")
-    idx = torch.from_numpy(buckets.astype(np.int64)).to(device)
-    return rpb.relative_attention_bias.weight[idx].permute(2, 0, 1)
+    key = (nf, str(device), rpb.num_buckets, rpb.max_distance, torch.is_inference_mode_enabled())
+    hit = getattr(rpb, "_vdmi_buckets", None)
+    if hit is None or hit[0] != key:          # the bucket indices depend on the frame count alone: one host pass and copy
+        buckets = np.empty((nf, nf), dtype=np.int32)
+        _lib.check(_lib.lib().vdmi_relpos_buckets(nf, rpb.num_buckets, rpb.max_distance, buckets.ctypes.data),
+                   "vdmi_relpos_buckets")
+        hit = (key, torch.from_numpy(buckets.astype(np.int64)).to(device))
+        object.__setattr__(rpb, "_vdmi_buckets", hit)
+    return rpb.relative_attention_bias.weight[hit[1]].permute(2, 0, 1)
 
 
 def _mask(shape, prob, device):
