@@ -2,9 +2,13 @@
 """Headline benchmark: DDPM sampling throughput of the Moving-MNIST-shape model on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                        # starts the N ranks itself (torch.distributed.run, one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      # or under a launcher
 
-    python -m torch.distributed.run ... bench.py --gpus N --global-batch 256       # BASELINE configs[2]
+    python bench.py --gpus N --global-batch 256         # BASELINE configs[2]
+
+A plain `--gpus N` is the weak-scaling run (BASELINE configs[1] on every GPU, 16 videos each); the strong-scaling
+run of configs[2] is asked for with `--global-batch 256`.
 
 One "step" = one denoise step (Unet3D forward + posterior update) over the local batch, replayed
 as one captured HIP graph.  Workload at every N: BASELINE.json configs[1] per GPU — Unet3D(dim=64,
@@ -120,6 +124,47 @@ def train_step_line(device, steps=5):
     return out
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) through
+    torch.distributed.run on a free local port and hand back its exit status.  The parent makes no GPU call, before
+    or after; rank 0 of the children prints the JSON line, which passes through on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # RCCL needs dmabuf IPC on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+    """VDMI_BENCH_DRY_RUN=1: the ranks only rendezvous (gloo, CPU) and rank 0 prints what the real run would be
+    launched as.  Exercises argument and launcher handling on a machine without a GPU."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        tt = torch.tensor([float(rank)])
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        ok = int(tt.item()) == world * (world - 1) // 2
+    else:
+        ok = True
+    if args.global_batch is not None and args.global_batch % world:
+        raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
+    batch = args.global_batch // world if args.global_batch is not None else args.batch
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size": world, "ranks_met": ok,
+                          "batch_per_gpu": batch, "global_batch": batch * world,
+                          "scaling": "strong" if args.global_batch is not None else "weak",
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,13 +181,17 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called plainly (`python bench.py --gpus N`): this process only starts the N ranks and waits for them
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch through `python -m torch.distributed.run --nproc-per-node N`")
+        raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}")
     import torch.distributed as dist
+    if os.environ.get("VDMI_BENCH_DRY_RUN") == "1":
+        raise SystemExit(dry_run(args, world, rank))
     # one rank per GPU; VDMI_BENCH_BACKEND=gloo lets several ranks rehearse the multi-rank path on one card
     backend = os.environ.get("VDMI_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
@@ -387,6 +436,7 @@ def main():
             "sample_steps_per_s": round(B * world * steps_per_s, 2),
             "model_tflops": round(154.5e9 * B * world * steps_per_s / 1e12, 1),
             "allgather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "world_size": world, "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
             "full_loop_s": None if full_loop_s is None else round(full_loop_s, 3),
             "videos_per_s_measured": None if full_loop_s is None else round(B * world / full_loop_s, 4),
             "roofline": roofline, "breakdown_ms_per_step": breakdown,

@@ -83,3 +83,41 @@ def test_small_modules_on_their_own_match_the_oracle():
     assert torch.equal(SinusoidalPosEmb(64)(t), O.sinusoidal_emb(t, 64))
     with pytest.raises(NotImplementedError):
         Block(64, 64)(torch.zeros(1, 64, 1, 8, 8))
+
+
+def _bench_dry(*argv, env_extra=None):
+    import json
+    env = dict(os.environ, VDMI_BENCH_DRY_RUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                       timeout=240)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_starts_its_own_ranks_when_called_plainly():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (torch.distributed.run on a free
+    local port); the dry-run mode makes the ranks only rendezvous over gloo, so this needs no GPU.  Exactly one JSON
+    line comes back (rank 0's), with the world size and the per-GPU batch of the weak-scaling default and of the
+    strong-scaling `--global-batch` form."""
+    r, out = _bench_dry("--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1 and out[0]["n_gpus"] == 2 and out[0]["ranks_met"]
+    assert out[0]["scaling"] == "weak" and out[0]["batch_per_gpu"] == 16 and out[0]["global_batch"] == 32
+    r, out = _bench_dry("--gpus", "2", "--global-batch", "256")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1 and out[0]["scaling"] == "strong" and out[0]["batch_per_gpu"] == 128
+    # a batch that does not divide over the ranks is refused by every rank, and the parent reports the failure
+    r, out = _bench_dry("--gpus", "2", "--global-batch", "255")
+    assert r.returncode != 0 and not out
+
+
+def test_bench_under_a_launcher_checks_the_world_size():
+    """Under torch.distributed.run the ranks find WORLD_SIZE in the environment and do not launch again; a
+    `--gpus` that disagrees with it is an error, not a silent single-rank run."""
+    r, out = _bench_dry("--gpus", "4", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    r, out = _bench_dry("--gpus", "1", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 0 and out and out[0]["n_gpus"] == 1
