@@ -162,6 +162,14 @@ void vdmi_wsconv_enable(int on);
  * label launches by the kernel that runs them). */
 int vdmi_wsconv_covers(const vdmi_tapgemm_args* a);
 
+/* HOST. vdmi_tapgemm runs the plain-epilogue (1,3,3) convolutions of 8-, 16- and 32-pixel-wide images with 64-channel
+ * input chunks and a multiple of 128 output channels (tile_bn = 64: Block.proj of the wide layers, vdp.py:412-420)
+ * on a streaming kernel (256-pixel x 128-channel tiles, patch and weights by LDS-DMA); 0 keeps them on the general
+ * tap-GEMM (tests and A/B timing; the environment variable VDMI_DCONV=0 does the same for a process). */
+void vdmi_dconv_enable(int on);
+/* 1 when vdmi_tapgemm would run this launch on the streaming kernel, else 0. */
+int vdmi_dconv_covers(const vdmi_tapgemm_args* a);
+
 /* ------------------------------------------------------------------------------------------
  * Cross-attention to previous-frame features: CrossAttention (vdp.py:480-528) inside
  * Residual(PreNorm(.)) at vdp.py:803-805 and :824-826, heads of 32 features.

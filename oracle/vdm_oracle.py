@@ -29,6 +29,22 @@ SD = Dict[str, Tensor]
 
 
 # --------------------------------------------------------------------------
+# rounding emulation (oracle/rounding_study.py): None = plain fp32, the pinned restatement.  Otherwise an object
+# with two callables: EMU.w(t) is applied to every weight of a convolution / projection of the denoiser, EMU.a(t)
+# to every activation where a reduced-precision implementation stores or feeds one (layer outputs, matrix operands).
+# --------------------------------------------------------------------------
+EMU = None
+
+
+def _rw(t: Tensor) -> Tensor:
+    return t if EMU is None else EMU.w(t)
+
+
+def _ra(t: Tensor) -> Tensor:
+    return t if EMU is None else EMU.a(t)
+
+
+# --------------------------------------------------------------------------
 # configuration (mirrors Unet3D.__init__ arguments, vdp.py:616-631)
 # --------------------------------------------------------------------------
 @dataclass
@@ -119,10 +135,14 @@ def _from_frames(y: Tensor, bf: Tuple[int, int]) -> Tensor:
     return y.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4)
 
 
-def conv_1kk(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int = 1, pad: int = 1) -> Tensor:
-    """Conv3d with kernel (1,k,k): a 2-D conv applied to every frame."""
-    xf, bf = _per_frame(x)
-    y = F.conv2d(xf, w[:, :, 0], bias, stride=stride, padding=pad)
+def conv_1kk(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int = 1, pad: int = 1, emu: bool = True) -> Tensor:
+    """Conv3d with kernel (1,k,k): a 2-D conv applied to every frame.  emu=False: never rounded by the rounding
+    emulation (the first and the last convolution of the denoiser run in fp32 arithmetic in every build)."""
+    if not emu:
+        xf, bf = _per_frame(x)
+        return _from_frames(F.conv2d(xf, w[:, :, 0], bias, stride=stride, padding=pad), bf)
+    xf, bf = _per_frame(_ra(x))
+    y = F.conv2d(xf, _rw(w[:, :, 0]), bias, stride=stride, padding=pad)
     return _from_frames(y, bf)
 
 
@@ -139,7 +159,7 @@ def block(sd: SD, p: str, x: Tensor, scale_shift: Optional[Tuple[Tensor, Tensor]
     if scale_shift is not None:
         sc, sh = scale_shift
         y = y * (sc + 1) + sh
-    return F.silu(y)
+    return _ra(F.silu(y)) if EMU is not None and getattr(EMU, "block_out", True) else F.silu(y)
 
 
 def resnet_block(sd: SD, p: str, x: Tensor, temb: Optional[Tensor]) -> Tensor:
@@ -158,7 +178,7 @@ def resnet_block(sd: SD, p: str, x: Tensor, temb: Optional[Tensor]) -> Tensor:
         res = conv_1kk(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"], pad=0)
     else:
         res = x
-    return h + res
+    return _ra(h + res)
 
 
 # --------------------------------------------------------------------------
@@ -207,7 +227,7 @@ def attention_tokens(x: Tensor, w_qkv: Tensor, w_out: Tensor, heads: int, dim_he
     vdp.py:590-600: in flagged samples a token attends only to itself.  All-False on the sampling path."""
     lead = x.shape[:-2]
     n = x.shape[-2]
-    qkv = F.linear(x, w_qkv)
+    qkv = F.linear(_ra(x), _rw(w_qkv))
     q, k, v = qkv.chunk(3, dim=-1)
 
     def split(t):
@@ -219,7 +239,7 @@ def attention_tokens(x: Tensor, w_qkv: Tensor, w_out: Tensor, heads: int, dim_he
         rot = rotary_interleaved if rotary == "interleaved" else rotary_half
         q = rot(q, min(32, dim_head))
         k = rot(k, min(32, dim_head))
-    sim = q @ k.transpose(-1, -2)
+    sim = _ra(q) @ _ra(k).transpose(-1, -2)
     if pos_bias is not None:
         sim = sim + pos_bias
     if focus is not None and bool(focus.any()):
@@ -228,9 +248,9 @@ def attention_tokens(x: Tensor, w_qkv: Tensor, w_out: Tensor, heads: int, dim_he
         sim = sim.masked_fill(~keep, -torch.finfo(sim.dtype).max)
     sim = sim - sim.amax(dim=-1, keepdim=True)
     attn = sim.softmax(dim=-1)
-    out = attn @ v
+    out = _ra(attn) @ _ra(v)
     out = out.transpose(-2, -3).reshape(*lead, n, heads * dim_head)
-    return F.linear(out, w_out)
+    return F.linear(_ra(out), _rw(w_out))
 
 
 def temporal_attn_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg, pos_bias: Tensor,
@@ -242,7 +262,7 @@ def temporal_attn_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg, pos_bias: Te
     o = attention_tokens(tok, sd[p + ".fn.fn.fn.to_qkv.weight"], sd[p + ".fn.fn.fn.to_out.weight"],
                          cfg.attn_heads, cfg.attn_dim_head, cfg.rotary, pos_bias, focus)
     o = o.reshape(b, h, w, f, c).permute(0, 4, 3, 1, 2)
-    return o + x
+    return _ra(o + x)
 
 
 def spatial_attn_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg) -> Tensor:
@@ -253,7 +273,7 @@ def spatial_attn_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg) -> Tensor:
     o = attention_tokens(tok, sd[p + ".fn.fn.fn.to_qkv.weight"], sd[p + ".fn.fn.fn.to_out.weight"],
                          cfg.attn_heads, 32, False, None)
     o = o.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3)
-    return o + x
+    return _ra(o + x)
 
 
 # --------------------------------------------------------------------------
@@ -276,14 +296,14 @@ def sla_residual(sd: SD, p: str, x: Tensor, cfg: UnetCfg) -> Tensor:
     heads, dh = cfg.attn_heads, 32
     y = layernorm_c(x, sd[p + ".fn.norm.gamma"])
     yf, bf = _per_frame(y)
-    qkv = F.conv2d(yf, sd[p + ".fn.fn.to_qkv.weight"])
+    qkv = F.conv2d(_ra(yf), _rw(sd[p + ".fn.fn.to_qkv.weight"]))
     q, k, v = qkv.reshape(b * f, 3, heads, dh, h * w).unbind(dim=1)    # each [bf, heads, d, n]
     q = q.softmax(dim=-2) * dh ** -0.5
     k = k.softmax(dim=-1)
-    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
-    out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(b * f, heads * dh, h, w)
-    out = F.conv2d(out, sd[p + ".fn.fn.to_out.weight"], sd[p + ".fn.fn.to_out.bias"])
-    return _from_frames(out, bf) + x
+    ctx = torch.einsum("bhdn,bhen->bhde", _ra(k), _ra(v))
+    out = torch.einsum("bhde,bhdn->bhen", _ra(ctx), _ra(q)).reshape(b * f, heads * dh, h, w)
+    out = F.conv2d(_ra(out), _rw(sd[p + ".fn.fn.to_out.weight"]), sd[p + ".fn.fn.to_out.bias"])
+    return _ra(_from_frames(out, bf) + x)
 
 
 # --------------------------------------------------------------------------
@@ -324,13 +344,13 @@ def frame_encoder(sd: SD, prev_latents: Tensor) -> Tensor:
 # A8  resamplers (vdp.py:374-378)
 # --------------------------------------------------------------------------
 def downsample(sd: SD, p: str, x: Tensor) -> Tensor:
-    return conv_1kk(x, sd[p + ".weight"], sd[p + ".bias"], stride=2, pad=1)
+    return _ra(conv_1kk(x, sd[p + ".weight"], sd[p + ".bias"], stride=2, pad=1))
 
 
 def upsample(sd: SD, p: str, x: Tensor) -> Tensor:
-    xf, bf = _per_frame(x)
-    y = F.conv_transpose2d(xf, sd[p + ".weight"][:, :, 0], sd[p + ".bias"], stride=2, padding=1)
-    return _from_frames(y, bf)
+    xf, bf = _per_frame(_ra(x))
+    y = F.conv_transpose2d(xf, _rw(sd[p + ".weight"][:, :, 0]), sd[p + ".bias"], stride=2, padding=1)
+    return _ra(_from_frames(y, bf))
 
 
 # --------------------------------------------------------------------------
@@ -354,7 +374,7 @@ def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
     bias = relpos_bias(sd["time_rel_pos_bias.relative_attention_bias.weight"], nf,
                        cfg.num_buckets, cfg.max_distance)
 
-    x = conv_1kk(x, sd["init_conv.weight"], sd["init_conv.bias"], pad=cfg.init_kernel_size // 2)
+    x = _ra(conv_1kk(x, sd["init_conv.weight"], sd["init_conv.bias"], pad=cfg.init_kernel_size // 2, emu=False))
     x = temporal_attn_residual(sd, "init_temporal_attn", x, cfg, bias)
     r = x
     t = time_mlp(sd, time, cfg.dim)
@@ -398,7 +418,7 @@ def unet3d_forward(sd: SD, cfg: UnetCfg, x: Tensor, time: Tensor,
 
     x = torch.cat((x, r), dim=1)
     x = resnet_block(sd, "final_conv.0", x, None)
-    return conv_1kk(x, sd["final_conv.1.weight"], sd["final_conv.1.bias"], pad=0)
+    return conv_1kk(x, sd["final_conv.1.weight"], sd["final_conv.1.bias"], pad=0, emu=False)
 
 
 # --------------------------------------------------------------------------

@@ -1050,3 +1050,59 @@ def test_errors_are_loud():
     m = make_unet(**TINY)
     with pytest.raises(Exception):
         m(torch.zeros(1, 3, 4, 8, 8), torch.zeros(1, dtype=torch.long))     # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("W,H,frames,c0,c1,n,ksplit", [
+    (8, 8, 10, 256, 0, 512, 1),        # four stacked frames per tile, last tile half empty
+    (8, 8, 8, 512, 0, 512, 3),         # contraction dealt to three workgroups per tile (unequal shares)
+    (8, 8, 12, 512, 512, 256, 4),      # two sources (skip concatenation)
+    (16, 16, 5, 128, 64, 256, 2),      # one frame per tile, two sources of different widths
+    (16, 32, 3, 64, 0, 128, 1),        # bands of a taller image: halo rows from the neighbouring band
+    (32, 32, 2, 128, 0, 128, 2),       # 8-row bands of a 32-pixel-wide image
+])
+def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, ksplit):
+    """The streaming (1,3,3) convolution of the wide layers (Block.proj, reference vdp.py:412-420) against the general
+    tap-GEMM on the same arguments and against torch's conv2d on the bf16-rounded operands.  Both kernels add the same
+    bf16 products in fp32 in the same order; they differ in when the bias joins the sum, so single roundings may flip."""
+    import ctypes as C
+    from video_diffusion_amd import _lib
+    from video_diffusion_amd.engine import PackedTaps, TAPS_3x3, _fill_pass
+    lib = _lib.lib()
+    cin = c0 + c1
+    wt = inp(f"dconv.w{W}.{cin}.{n}", (n, cin, 9), scale=(9 * cin) ** -0.5)
+    bias = inp(f"dconv.b{n}", (n,), scale=0.1).to(dev())
+    pk = PackedTaps(wt, c0, c1, _lib.EPI_PLAIN, dev(), tile_bn=64)
+    x0 = inp(f"dconv.x0.{W}.{c0}", (frames * H * W, c0)).to(torch.bfloat16).to(dev())
+    x1 = inp(f"dconv.x1.{W}.{c1}", (frames * H * W, c1)).to(torch.bfloat16).to(dev()) if c1 else None
+    rows = frames * H * W
+
+    def run(enable):
+        out = torch.full((ksplit * rows, n), float("nan"), device=dev(), dtype=torch.bfloat16)
+        a = _lib.TapGemmArgs()
+        a.frames, a.frames_per_batch = frames, frames
+        a.grid_h, a.grid_w, a.out_h, a.out_w = H, W, H, W
+        a.out_mul = 1
+        a.out, a.ldo, a.n, a.epilogue = out.data_ptr(), n, n, _lib.EPI_PLAIN
+        _fill_pass(a.main, x0, c0, x1, c1, H, W, 1, TAPS_3x3, pk.data)
+        a.bias = bias.data_ptr()
+        a.tile_bn = 64
+        if ksplit > 1:
+            a.k_split, a.out_split_stride = ksplit, rows * n
+        lib.vdmi_dconv_enable(1 if enable else 0)
+        try:
+            assert lib.vdmi_dconv_covers(C.byref(a)) == (1 if enable else 0)
+            _lib.check(lib.vdmi_tapgemm(C.byref(a), torch.cuda.current_stream().cuda_stream), "vdmi_tapgemm")
+            torch.cuda.synchronize()
+        finally:
+            lib.vdmi_dconv_enable(1)
+        return out.float().reshape(ksplit, rows, n).sum(0).cpu()
+
+    y_new, y_old = run(True), run(False)
+    assert torch.isfinite(y_new).all()
+    x = torch.cat([t.float().cpu() for t in (x0, x1) if t is not None], dim=1)
+    xi = x.reshape(frames, H, W, cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xi, bf16_round(wt).reshape(n, cin, 3, 3), bias.cpu(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(rows, n)
+    assert rel_err(y_new, ref) < 4e-3 * max(1, ksplit) ** 0.5        # one bf16 rounding per partial sum
+    assert rel_err(y_new, y_old) < 2e-3
+    assert (y_new != y_old).float().mean() < 0.05

@@ -82,6 +82,8 @@ _SIGNATURES = {
     "vdmi_tapgemm": (C.c_int, [C.POINTER(TapGemmArgs), C.c_void_p]),
     "vdmi_wsconv_enable": (None, [C.c_int]),
     "vdmi_wsconv_covers": (C.c_int, [C.c_void_p]),
+    "vdmi_dconv_enable": (None, [C.c_int]),
+    "vdmi_dconv_covers": (C.c_int, [C.c_void_p]),
     "vdmi_attn_core": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vdmi_pack_tattn_elems": (C.c_size_t, [C.c_int, C.c_int]),

@@ -890,6 +890,7 @@ extern "C" int vdmi_tapgemm_tile(int epilogue, int n, int* bn, int* bkc) {
 }
 
 int vdmi_wsconv_try(const vdmi_tapgemm_args& A, hipStream_t stream);   // wsconv.hip
+int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream);    // dconv.hip
 
 extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) {
     if (!args || !args->out) return VDMI_E_ARG;
@@ -918,6 +919,12 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if (epi == VDMI_EPI_NORM_SILU) {
         const int ws = vdmi_wsconv_try(A, stream);
         if (ws <= 0) return ws;
+    }
+
+    // (1,3,3) convolutions of the wide, small-image layers: the streaming kernel
+    if (epi == VDMI_EPI_PLAIN && A.tile_bn == 64) {
+        const int dc = vdmi_dconv_try(A, stream);
+        if (dc <= 0) return dc;
     }
 
     TileCfg cands[4];

@@ -149,7 +149,8 @@ class Plan:
         k = (a.main.c0 + a.main.c1) * a.main.ntaps + ((a.res.c0 + a.res.c1) if a.has_res == 1 else 0)
         bn = 64 if a.tile_bn == 64 else tile_for(a.epilogue, a.n)[0]
         in_rows = a.frames * a.main.in_h * a.main.in_w
-        kernel = "wsconv64" if lib.vdmi_wsconv_covers(C.byref(a)) else f"tapgemm<epi={a.epilogue},bn={bn}>"
+        kernel = ("wsconv64" if lib.vdmi_wsconv_covers(C.byref(a)) else
+                  "dconv" if lib.vdmi_dconv_covers(C.byref(a)) else f"tapgemm<epi={a.epilogue},bn={bn}>")
         meta = {"kernel": kernel, "flops": 2.0 * m * a.n * k,
                 "bytes": 2.0 * (in_rows * (a.main.c0 + a.main.c1) / (4 if a.main.space_to_depth else 1)
                                 + m * a.n + a.n * k)}
@@ -224,7 +225,8 @@ class Plan:
         ksplit = 1
         if K_SPLIT_BELOW and wgs < K_SPLIT_BELOW:
             ksplit = min(4, max(1, K_SPLIT_TARGET // wgs), (c0 + c1) // 64)
-            ksplit = 1 if ksplit < 2 else (2 if ksplit < 4 else 4)
+            if not (K_SPLIT_ODD and ksplit == 3):
+                ksplit = 1 if ksplit < 2 else (2 if ksplit < 4 else 4)
         raw = self._buf(ksplit * rows, n)
         a = self._base_args(frames, h, w, raw, n, EPI_PLAIN)
         _fill_pass(a.main, s0, c0, s1, c1, h, w, 1, TAPS_3x3, w_pack.data)
@@ -687,6 +689,7 @@ TATTN_WIDE_BELOW_HW = int(os.environ.get("VDMI_TATTN_WIDE_BELOW_HW", str(1 << 30
 # wide-layer convs that would launch fewer workgroups than this split their contraction (0: never)
 K_SPLIT_BELOW = int(os.environ.get("VDMI_K_SPLIT_BELOW", "256"))
 K_SPLIT_TARGET = int(os.environ.get("VDMI_K_SPLIT_TARGET", "320"))      # workgroups per launch the split aims at
+K_SPLIT_ODD = os.environ.get("VDMI_K_SPLIT_ODD", "0") != "0"           # allow a three-way split (unequal shares of the chunks)
 # SpatialLinearAttention at 256 channels on frames of more than 64 positions: the one-launch two-sweep kernel
 SLA_WIDE_LONG = os.environ.get("VDMI_SLA_WIDE_LONG", "1") != "0"
 SPLIT_LONG_K = int(os.environ.get("VDMI_SPLIT_LONG_K", "512"))      # input channels from which such a block takes the split form (0: never)
