@@ -212,6 +212,7 @@ def main():
         args.batch = args.global_batch // world
 
     from video_diffusion_amd import engine as vd_engine
+    from video_diffusion_amd import _lib as vd_lib      # VDMI_PRECISION=f16 benches the IEEE-half build; default bf16
     if args.parts is not None:
         vd_engine.BATCH_PARTS = args.parts
     parts = vd_engine.batch_parts(args.batch)
@@ -422,7 +423,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if args.global_batch is not None else "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": vd_lib.PRECISION, "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[2]: Unet3D(dim=64,dim_mults=(1,2,4,8),channels=1), global batch "
                                     f"{args.global_batch} sharded over {world} GPU(s) = x=({B},1,10,64,64) per GPU, "
                                     "T=1000, random-init weights") if args.global_batch is not None else

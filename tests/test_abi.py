@@ -32,6 +32,29 @@ def test_library_exports_every_declared_symbol():
     assert b"shape" in lib.vdmi_strerror(-2)
 
 
+def test_half_precision_library_exports_the_same_symbols_and_packs_ieee_half():
+    """libvdmi_f16.so is the same sources built with IEEE half in place of bfloat16 (VDMI_PRECISION=f16 selects it):
+    same entry points; its host-side packer rounds weights to half, the default library's to bfloat16."""
+    path = os.path.join(os.path.dirname(_lib.__file__), "libvdmi_f16.so")
+    assert os.path.exists(path), "build it with make -C video_diffusion_amd/csrc"
+    h16 = C.CDLL(path)
+    for n in declared_symbols():
+        assert hasattr(h16, n), n
+    w = np.array([[[1.0 + 2.0 ** -9]]], dtype=np.float32)        # exact in half (10 fraction bits), not in bfloat16 (7)
+    w = np.tile(w, (32, 16, 1)).astype(np.float32)
+    outs = {}
+    for name, lib in (("f16", h16), ("bf16", C.CDLL(os.path.join(os.path.dirname(_lib.__file__), "libvdmi.so")))):
+        lib.vdmi_pack_taps_elems.restype = C.c_size_t
+        lib.vdmi_pack_taps_elems.argtypes = [C.c_int] * 6
+        lib.vdmi_pack_taps.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]
+        elems = lib.vdmi_pack_taps_elems(32, 64, 16, 0, 1, 64)
+        out = np.zeros(elems, dtype=np.uint16)
+        assert lib.vdmi_pack_taps(w.ctypes.data, 32, 64, 16, 0, 1, 64, out.ctypes.data, None) == 0
+        outs[name] = out
+    assert float(torch.from_numpy(outs["f16"][:1].view(np.int16)).view(torch.float16)[0]) == 1.0 + 2.0 ** -9
+    assert float(torch.from_numpy(outs["bf16"][:1].view(np.int16)).view(torch.bfloat16)[0]) == 1.0
+
+
 def test_relpos_buckets_match_reference():
     lib = _lib.lib()
     g = golden("relpos_buckets")

@@ -10,6 +10,8 @@ import torch
 
 from tests.helpers import CFG0, CFG1, CFG3, TINY, TINY_COND, golden, inp, make_unet, record, rel_err
 
+from video_diffusion_amd._lib import PRECISION
+
 pytestmark = pytest.mark.gpu
 
 MODEL_TOL = 2e-2
@@ -101,7 +103,8 @@ def test_cfg0_full_loop_T250_vs_reference():
     e_auto = record("cfg0_full_loop_T250_final_sample_reference_autocast_bf16", rel_err(ga["final"], g["final"]), None)
     e_round = record("cfg0_full_loop_T250_final_sample_reference_eps_rounded_to_bf16",
                      rel_err(g["final_bf16eps"], g["final"]), None)
-    bar = 2.0 * e_auto
+    # the IEEE-half build (VDMI_PRECISION=f16) is held to the stated tolerance itself: 2e-2 on the final sample
+    bar = 2e-2 if PRECISION == "f16" else 2.0 * e_auto
     assert e_round < 2e-3
     assert record("cfg0_full_loop_T250_final_sample", rel_err(out.cpu(), g["final"]), bar) < bar
 

@@ -12,6 +12,8 @@ import torch
 from oracle import vdm_oracle as O
 from tests.helpers import (CFG0, CFG1, CFG3, TINY, TINY_COND, golden, inp, make_unet, oracle_cfg, record, rel_err)
 
+from video_diffusion_amd._lib import ACT_DTYPE as ACT      # storage type of the library under test (bf16, or f16 with VDMI_PRECISION=f16)
+
 pytestmark = pytest.mark.gpu
 
 LAYER_TOL = 1e-2
@@ -26,7 +28,7 @@ def dev():
 def to_rows(x):
     """(B, C, F, H, W) float32 -> channels-last bf16 rows [B*F*H*W][C] on the GPU."""
     b, c, f, h, w = x.shape
-    return x.permute(0, 2, 3, 4, 1).reshape(-1, c).to(torch.bfloat16).to(dev()).contiguous()
+    return x.permute(0, 2, 3, 4, 1).reshape(-1, c).to(ACT).to(dev()).contiguous()
 
 
 def from_rows(y, b, f, h, w):
@@ -35,7 +37,7 @@ def from_rows(y, b, f, h, w):
 
 
 def bf16_round(x):
-    return x.to(torch.bfloat16).float()
+    return x.to(ACT).float()
 
 
 class Layers:
@@ -137,7 +139,7 @@ def test_init_conv(tiny):
     L, g, B, Fr, H = tiny["L"], tiny["g"], tiny["B"], tiny["F"], tiny["H"]
     x = inp("tiny.x", (B, 3, Fr, H, H)).to(dev())
     ic = L.eng.packed["init_conv"]
-    out = torch.empty(B * Fr * H * H, 32, device=dev(), dtype=torch.bfloat16)
+    out = torch.empty(B * Fr * H * H, 32, device=dev(), dtype=ACT)
     _lib.check(_lib.lib().vdmi_init_conv(x.data_ptr(), ic["w"].data_ptr(), ic["b"].data_ptr(), out.data_ptr(),
                                          B, 3, Fr, H, H, 32, 7, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
@@ -221,8 +223,8 @@ def test_rmsnorm_silu_rows(c, rows, with_res, with_shift):
     from video_diffusion_amd import _lib
     rpb = 100
     nb = (rows + rpb - 1) // rpb
-    x = inp(f"rms.x{c}", (rows, c), scale=2.0).to(torch.bfloat16)
-    res = inp(f"rms.r{c}", (rows, c)).to(torch.bfloat16) if with_res else None
+    x = inp(f"rms.x{c}", (rows, c), scale=2.0).to(ACT)
+    res = inp(f"rms.r{c}", (rows, c)).to(ACT) if with_res else None
     gain = (1.0 + 0.5 * inp(f"rms.g{c}", (nb, c))).contiguous()
     shift = inp(f"rms.s{c}", (nb, c)).contiguous() if with_shift else None
     xd, gd = x.to(dev()), gain.to(dev())
@@ -420,17 +422,17 @@ def test_xattn_core_vs_torch(L, rps, nb, heads):
     from video_diffusion_amd import _lib
     lib = _lib.lib()
     hid, nl = heads * 32, 2
-    q = (0.5 * inp(f"xa.q{L}", (nb * rps, hid))).to(torch.bfloat16)
-    kv = (1.5 * inp(f"xa.kv{L}", (nb * L, nl * 2 * hid))).to(torch.bfloat16)
+    q = (0.5 * inp(f"xa.q{L}", (nb * rps, hid))).to(ACT)
+    kv = (1.5 * inp(f"xa.kv{L}", (nb * L, nl * 2 * hid))).to(ACT)
     qd, kvd = q.to(dev()), kv.to(dev())
     per = lib.vdmi_xattn_kv_elems(1, nb, L, heads)
     assert lib.vdmi_xattn_kv_elems(nl, nb, L, heads) == nl * per
-    pack = torch.empty(nl * per, device=dev(), dtype=torch.bfloat16)
+    pack = torch.empty(nl * per, device=dev(), dtype=ACT)
     s = torch.cuda.current_stream().cuda_stream
     _lib.check(lib.vdmi_xattn_pack_kv(kvd.data_ptr(), nl * 2 * hid, pack.data_ptr(), nl, nb, L, heads, s))
     perm = torch.tensor([32 * hd + (r & 3) + 8 * (r >> 2) + 4 * hh for hd in range(heads) for hh in (0, 1) for r in range(16)])
     for layer in range(nl):
-        o = torch.empty(nb * rps, hid, device=dev(), dtype=torch.bfloat16)
+        o = torch.empty(nb * rps, hid, device=dev(), dtype=ACT)
         _lib.check(lib.vdmi_xattn_core(qd.data_ptr(), hid, o.data_ptr(), pack.data_ptr() + layer * per * 2, nb, rps, L, heads, s))
         torch.cuda.synchronize()
         qf = q.float().reshape(nb, rps, heads, 32).transpose(1, 2)
@@ -589,7 +591,7 @@ def test_temporal_dwconv_vs_torch(c, k, f, hw, nb):
     """vdmi_temporal_dwconv against torch's grouped Conv3d on the same bf16 rows."""
     from video_diffusion_amd import _lib
     lib = _lib.lib()
-    x = inp(f"dw.x{c}", (nb * f * hw, c)).to(torch.bfloat16)
+    x = inp(f"dw.x{c}", (nb * f * hw, c)).to(ACT)
     w = (0.5 * inp(f"dw.w{c}", (c, k))).contiguous()
     b = (0.1 * inp(f"dw.b{c}", (c,))).contiguous()
     xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())
@@ -608,8 +610,8 @@ def test_groupnorm_general_form():
     from video_diffusion_amd import _lib
     lib = _lib.lib()
     c, groups, rows, nb = 128, 8, 600, 2
-    x = (inp("gn2.x", (nb * rows, c), scale=2.0) + 0.3).to(torch.bfloat16)
-    res = inp("gn2.r", (nb * rows, c)).to(torch.bfloat16)
+    x = (inp("gn2.x", (nb * rows, c), scale=2.0) + 0.3).to(ACT)
+    res = inp("gn2.r", (nb * rows, c)).to(ACT)
     gamma, beta = (1.0 + 0.3 * inp("gn2.g", (c,))).contiguous(), (0.2 * inp("gn2.b", (c,))).contiguous()
     pg, ps = (1.0 + 0.5 * inp("gn2.pg", (nb, c + 8))).contiguous(), inp("gn2.ps", (nb, c + 8)).contiguous()
     d = dev()
@@ -662,7 +664,7 @@ def test_groupnorm_silu_rows(c, groups, rows, nb):
     """vdmi_groupnorm_silu against torch.nn.functional.group_norm + SiLU on the same bf16-rounded rows."""
     from video_diffusion_amd import _lib
     lib = _lib.lib()
-    x = (inp(f"gn.x{c}", (nb * rows, c), scale=2.0) + 0.3).to(torch.bfloat16)
+    x = (inp(f"gn.x{c}", (nb * rows, c), scale=2.0) + 0.3).to(ACT)
     gamma = (1.0 + 0.3 * inp(f"gn.g{c}", (c,))).contiguous()
     beta = (0.2 * inp(f"gn.b{c}", (c,))).contiguous()
     xd, gd_, bd = x.to(dev()), gamma.to(dev()), beta.to(dev())
@@ -963,7 +965,9 @@ def test_cfg3_cfg_eps_vs_reference():
     x, c = inp("cfg3.x", (1, 3, 16, 64, 64)).to(dev()), inp("cfg3.cond", (1, 768)).to(dev())
     with torch.no_grad():
         eps = m.forward_with_cond_scale(x, g["t"].to(dev()), cond=c, cond_scale=2.0)
-    assert record("cfg3_eps_guided_scale2", rel_err(eps.cpu(), g["eps_cfg2"]), 2 * MODEL_TOL) < 2 * MODEL_TOL   # guidance doubles the difference term
+    # guidance doubles the difference term of two bf16 results; the IEEE-half build is held to the tolerance itself
+    bar = MODEL_TOL if ACT == torch.float16 else 2 * MODEL_TOL
+    assert record("cfg3_eps_guided_scale2", rel_err(eps.cpu(), g["eps_cfg2"]), bar) < bar
 
 
 @pytest.mark.parametrize("parts", [2, 3, 4])
@@ -1072,12 +1076,12 @@ def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, kspli
     wt = inp(f"dconv.w{W}.{cin}.{n}", (n, cin, 9), scale=(9 * cin) ** -0.5)
     bias = inp(f"dconv.b{n}", (n,), scale=0.1).to(dev())
     pk = PackedTaps(wt, c0, c1, _lib.EPI_PLAIN, dev(), tile_bn=64)
-    x0 = inp(f"dconv.x0.{W}.{c0}", (frames * H * W, c0)).to(torch.bfloat16).to(dev())
-    x1 = inp(f"dconv.x1.{W}.{c1}", (frames * H * W, c1)).to(torch.bfloat16).to(dev()) if c1 else None
+    x0 = inp(f"dconv.x0.{W}.{c0}", (frames * H * W, c0)).to(ACT).to(dev())
+    x1 = inp(f"dconv.x1.{W}.{c1}", (frames * H * W, c1)).to(ACT).to(dev()) if c1 else None
     rows = frames * H * W
 
     def run(enable):
-        out = torch.full((ksplit * rows, n), float("nan"), device=dev(), dtype=torch.bfloat16)
+        out = torch.full((ksplit * rows, n), float("nan"), device=dev(), dtype=ACT)
         a = _lib.TapGemmArgs()
         a.frames, a.frames_per_batch = frames, frames
         a.grid_h, a.grid_w, a.out_h, a.out_w = H, W, H, W

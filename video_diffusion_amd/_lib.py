@@ -7,8 +7,17 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VDMI_LIB_PATH") or os.path.join(_HERE, "libvdmi.so")
+# Precision of the kernels' storage and matrix operands, one per process: "bf16" (default; libvdmi.so) or "f16"
+# (VDMI_PRECISION=f16; libvdmi_f16.so: the same kernels built with IEEE half in place of bfloat16 - 11 significant
+# bits instead of 8 at the same speed class, for loops whose final sample must stay within 2e-2 of fp32).
+PRECISION = os.environ.get("VDMI_PRECISION", "bf16").lower()
+if PRECISION not in ("bf16", "f16"):
+    raise ValueError(f"VDMI_PRECISION={PRECISION!r}: expected 'bf16' or 'f16'")
+ACT_DTYPE = torch.float16 if PRECISION == "f16" else torch.bfloat16
+LIB_PATH = os.environ.get("VDMI_LIB_PATH") or os.path.join(_HERE, "libvdmi_f16.so" if PRECISION == "f16" else "libvdmi.so")
 
 MAX_TAPS = 16
 EPI_PLAIN, EPI_NORM_SILU, EPI_QKV_ATTN, EPI_QKV_SLA = 0, 1, 2, 3

@@ -3,24 +3,13 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/vdmi.h"
+#include "vdmi_common.h"
 
 namespace {
 
-inline uint16_t f32_to_bf16_rne(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+inline uint16_t f32_to_bf16_rne(float f) { return vdmi_host_half_bits(f); }
 
-inline float bf16_to_f32(uint16_t h) {
-    uint32_t u = (uint32_t)h << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-}
+inline float bf16_to_f32(uint16_t h) { return vdmi_host_half_value(h); }
 
 }   // namespace
 

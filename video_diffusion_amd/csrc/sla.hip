@@ -349,13 +349,7 @@ __global__ __launch_bounds__(512, 2) void sla_pass2_kernel(const SlaArgs a) {
     }
 }
 
-inline uint16_t host_bf16(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+inline uint16_t host_bf16(float f) { return vdmi_host_half_bits(f); }
 
 // The split of a frame's positions into parts depends on hw only (never on the batch), so a
 // sample's result is bit-identical however the batch is sharded.

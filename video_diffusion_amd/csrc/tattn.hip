@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
             const int kf = row % F, site = valid ? row / F : g;
             float v = 0.f;
             if (slot < F) v = (valid && a.bias) ? a.bias[(head * F + slot) * F + kf] * LOG2E : 0.f;
-            else if (slot < F + g + 1) v = (slot - F == site) ? 1125899906842624.f : 0.f;      // 2^50
+            else if (slot < F + g + 1) v = (slot - F == site) ? VDMI_MASK_BIG : 0.f;      // 2^50
             kxl[i] = f2bf(v);
         }
     } else {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
             const int slot = 8 * half + j;
             float v = 0.f;
             if (slot < F) v = (slot == q_f) ? 1.f : 0.f;
-            else if (slot < F + g + 1) v = (slot - F == qs_idx) ? 0.f : -1125899906842624.f;
+            else if (slot < F + g + 1) v = (slot - F == qs_idx) ? 0.f : -VDMI_MASK_BIG;
             qx[j] = f2bf(v);
         }
     }
@@ -359,13 +359,7 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
 // k-slot -> accumulator-row order of v_mfma_f32_32x32x16_bf16 (k-step s, element j, lane half h)
 static inline int slot_row(int s, int j, int h) { return (j & 3) + 16 * s + 8 * (j >> 2) + 4 * h; }
 
-static inline uint16_t host_bf16(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+static inline uint16_t host_bf16(float f) { return vdmi_host_half_bits(f); }
 
 extern "C" size_t vdmi_pack_tattn_elems(int c, int heads) {
     return (size_t)heads * (3 * (c / 16) + 2 * (c / 32)) * 512;

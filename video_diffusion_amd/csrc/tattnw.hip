@@ -78,7 +78,7 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
             const int kf = row % F, site = valid ? row / F : g;
             float v = 0.f;
             if (slot < F) v = (valid && a.bias) ? a.bias[(hd * F + slot) * F + kf] * LOG2E : 0.f;
-            else if (slot < F + g + 1) v = (slot - F == site) ? 1125899906842624.f : 0.f;      // 2^50
+            else if (slot < F + g + 1) v = (slot - F == site) ? VDMI_MASK_BIG : 0.f;      // 2^50
             kxl[i] = f2bf(v);
         }
     } else {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
             const int slot = 8 * half + j;
             float v = 0.f;
             if (slot < F) v = (slot == q_f) ? 1.f : 0.f;
-            else if (slot < F + g + 1) v = (slot - F == qs_idx) ? 0.f : -1125899906842624.f;
+            else if (slot < F + g + 1) v = (slot - F == qs_idx) ? 0.f : -VDMI_MASK_BIG;
             qx[j] = f2bf(v);
         }
     }

@@ -6,6 +6,53 @@
 #include <stdint.h>
 #include "../../include/vdmi.h"
 
+// Precision build.  The default library stores activations and weights as bfloat16 and multiplies them with
+// v_mfma_f32_32x32x16_bf16.  Built with -DVDMI_F16 (libvdmi_f16.so) every "bf16" in these sources is IEEE half
+// instead: same storage bytes, same matrix-core rate, same fp32 accumulation, but 11 significant bits where bfloat16
+// carries 8 (and a range of 65504, which the normalised activations of the denoiser stay far inside).  The type and
+// the MFMA are switched here, once, for every kernel and for the host-side packers.
+#ifdef VDMI_F16
+#define __bf16 _Float16
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#endif
+
+// HOST: float -> the 16 bits of the library's storage type, round to nearest even (NaN stays NaN).
+static inline uint16_t vdmi_host_half_bits(float f) {
+#ifdef VDMI_F16
+    const _Float16 hv = (_Float16)f;
+    uint16_t r;
+    __builtin_memcpy(&r, &hv, 2);
+    return r;
+#else
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+#endif
+}
+// HOST: the float value of those 16 bits
+static inline float vdmi_host_half_value(uint16_t h) {
+#ifdef VDMI_F16
+    _Float16 hv;
+    __builtin_memcpy(&hv, &h, 2);
+    return (float)hv;
+#else
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
+// Largest power of two that the site-mask trick of the fused temporal attention may put into a 16-bit operand: a key of
+// another site scores -(VDMI_MASK_BIG^2), which exp2 turns into an exact zero (2^50 in bfloat16; IEEE half ends at 65504).
+#ifdef VDMI_F16
+#define VDMI_MASK_BIG 32768.f
+#else
+#define VDMI_MASK_BIG 1125899906842624.f
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

@@ -57,7 +57,7 @@ class PackedTaps:
         colsum = torch.empty(n, dtype=torch.float32) if want_colsum else None
         check(lib.vdmi_pack_taps(w.data_ptr(), n, self.npad, cin0, cin1, ntaps, self.bkc, out.data_ptr(),
                                  _ptr(colsum)), "vdmi_pack_taps")
-        self.data = out.view(torch.bfloat16).to(device)
+        self.data = out.view(_lib.ACT_DTYPE).to(device)
         self.colsum = colsum.to(device) if want_colsum else None
 
 
@@ -133,7 +133,7 @@ class Plan:
         return t
 
     def _buf(self, rows: int, ch: int) -> torch.Tensor:
-        t = torch.empty(rows, ch, device=self.device, dtype=torch.bfloat16)
+        t = torch.empty(rows, ch, device=self.device, dtype=_lib.ACT_DTYPE)
         self.keep.append(t)
         return t
 
@@ -344,7 +344,7 @@ class Plan:
         a.colsum = _ptr(st["wqkv"].colsum)
         a.ln_eps, a.q_scale = 1e-5, st["scale"] * math.log2(math.e)
         self._tapgemm(a, name + ".qkv")
-        kvp = torch.empty(lib.vdmi_xattn_kv_elems(1, ngrp, n_tok, heads), device=self.device, dtype=torch.bfloat16)
+        kvp = torch.empty(lib.vdmi_xattn_kv_elems(1, ngrp, n_tok, heads), device=self.device, dtype=_lib.ACT_DTYPE)
         self.keep.append(kvp)
         self._add(lambda s, qkv=qkv: lib.vdmi_xattn_pack_kv(qkv.data_ptr() + 2 * hid, 3 * hid, kvp.data_ptr(), 1, ngrp,
                                                             n_tok, heads, s), None, name + ".pack_kv")
@@ -432,7 +432,7 @@ class Plan:
                 meta, name + ".fused")
             return y
         qs = self._buf(rows, hid)
-        kvt = torch.empty(frames, 2 * hid, hw, device=self.device, dtype=torch.bfloat16)
+        kvt = torch.empty(frames, 2 * hid, hw, device=self.device, dtype=_lib.ACT_DTYPE)
         self.keep.append(kvt)
         a = self._base_args(frames, h, w, qs, 3 * hid, EPI_QKV_SLA)
         _fill_pass(a.main, x, c, None, 0, h, w, 1, [(0, 0)], sl["wqkv"].data)
@@ -442,7 +442,7 @@ class Plan:
         self._tapgemm(a, name + ".qkv")
         bn, bkc = tile_for(EPI_PLAIN, c)
         cpad = (c + bn - 1) // bn * bn
-        wf = torch.zeros(frames, hid * cpad, device=self.device, dtype=torch.bfloat16)
+        wf = torch.zeros(frames, hid * cpad, device=self.device, dtype=_lib.ACT_DTYPE)
         self.keep.append(wf)
         wout = sl["wout_f32"]
         self._add(lambda s, kvt=kvt, wf=wf: lib.vdmi_sla_context(
@@ -467,7 +467,7 @@ class Plan:
         ctx_rows = self._buf(B * L, D)
         kv_rows = self._buf(B * L, nl * 2 * hid)
         self.kv_layer_elems = lib.vdmi_xattn_kv_elems(1, B, L, hid // 32)
-        self.kv_pack = torch.empty(nl * self.kv_layer_elems, device=dev, dtype=torch.bfloat16)
+        self.kv_pack = torch.empty(nl * self.kv_layer_elems, device=dev, dtype=_lib.ACT_DTYPE)
         calls, self.calls = self.calls, self.ctx_calls
         self._add(lambda s: lib.vdmi_xattn_context(self.ctx_in.data_ptr(), self.ctx_keep.data_ptr(), ctx_rows.data_ptr(),
                                                    B, L, D, s), None, "xattn.context")
@@ -888,7 +888,7 @@ class UnetEngine:
             wo = att.to_out.weight.detach().float().cpu().contiguous()
             wqc = wq.contiguous()
             check(lib.vdmi_pack_tattn(wqc.data_ptr(), wo.data_ptr(), cdim, hid // 32, buf.data_ptr()), "vdmi_pack_tattn")
-            fused = buf.view(torch.bfloat16).to(device)
+            fused = buf.view(_lib.ACT_DTYPE).to(device)
         return {
             "fused": fused,
             "wqkv": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_ATTN, device, want_colsum=True),
@@ -941,7 +941,7 @@ class UnetEngine:
             buf = torch.empty(lib.vdmi_pack_tattn_elems(cdim, hid // 32), dtype=torch.int16)
             wqc, won = wq.contiguous(), st.to_out.weight.detach().float().cpu().contiguous()
             check(lib.vdmi_pack_tattn(wqc.data_ptr(), won.data_ptr(), cdim, hid // 32, buf.data_ptr()), "vdmi_pack_tattn")
-            fused = buf.view(torch.bfloat16).to(device)
+            fused = buf.view(_lib.ACT_DTYPE).to(device)
         return {"sta": True, "hid": hid, "scale": float(st.scale), "fused": fused,
                 "wqkv": PackedTaps(wq[:, :, None], wq.shape[1], 0, EPI_QKV_ATTN, device, want_colsum=True),
                 "wout": PackedTaps(wo[:, :, None], hid, 0, EPI_PLAIN, device)}
@@ -961,7 +961,7 @@ class UnetEngine:
             buf = torch.empty(lib.vdmi_pack_sla_elems(cdim, hid // 32), dtype=torch.int16)
             wqc = wq.contiguous()
             check(lib.vdmi_pack_sla(wqc.data_ptr(), cdim, hid // 32, buf.data_ptr()), "vdmi_pack_sla")
-            fused = buf.view(torch.bfloat16).to(device)
+            fused = buf.view(_lib.ACT_DTYPE).to(device)
         fused_wide = None
         if cdim in (256, 512) and hid == 256 and TATTN_WIDE_BELOW_HW:
             # frames of at most 64 positions: the one-launch kernel (weights in vdmi_pack_tattn order)
@@ -970,7 +970,7 @@ class UnetEngine:
             wqc = wq.contiguous()
             won = sl.to_out.weight.detach().float().cpu().reshape(sl.to_out.weight.shape[0], -1).contiguous()
             check(lib.vdmi_pack_tattn(wqc.data_ptr(), won.data_ptr(), cdim, hid // 32, buf.data_ptr()), "vdmi_pack_tattn")
-            fused_wide = buf.view(torch.bfloat16).to(device)
+            fused_wide = buf.view(_lib.ACT_DTYPE).to(device)
         return {
             "fused": fused,
             "fused_wide": fused_wide,

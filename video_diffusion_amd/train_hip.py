@@ -405,6 +405,8 @@ def resnet_block(rb, x: torch.Tensor, temb) -> torch.Tensor:
 def supports(unet) -> bool:
     """True when every ResnetBlock, attention layer and resampling convolution of `unet` has a shape the training kernels
     take (channel widths powers of two from 64 to 2048, heads of 32 features): what `train_backend = "hip"` needs."""
+    if _lib.PRECISION != "bf16":     # the training layers exchange bfloat16 rows; the IEEE-half build serves sampling only
+        return False
     ok = lambda c: 64 <= c <= 2048 and (c & (c - 1)) == 0
     try:
         return _supports(unet, ok)

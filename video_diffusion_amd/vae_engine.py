@@ -52,7 +52,7 @@ class _ConvPlan:
         self.keep, self.calls = [], []
 
     def buf(self, rows, ch):
-        t = torch.empty(rows, ch, device=self.device, dtype=torch.bfloat16)
+        t = torch.empty(rows, ch, device=self.device, dtype=_lib.ACT_DTYPE)
         self.keep.append(t)
         return t
 
