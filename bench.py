@@ -88,10 +88,10 @@ def cpu_baseline(batch, steps):
             "denoise_steps_per_s": steps_per_s}
 
 
-def train_step_line(device, steps=5):
+def train_step_line(device, steps=5, torch_leg=False):
     """BASELINE configs[4]: loss forward + backward of Unet3D(dim=128, channels=3) on (1,3,16,128,128)
-    (reference vdp.py:1146-1161, 1451), on the HIP training kernels and on torch ops, both under bf16 autocast.
-    Reported beside the sampling metric, outside its timed region."""
+    (reference vdp.py:1146-1161, 1451) on the HIP training kernels, under bf16 autocast (torch_leg: also the same step
+    as torch ops, which run the convolutions on MIOpen).  Reported beside the sampling metric, outside its timed region."""
     import torch.nn.functional as F
     from video_diffusion_amd import Unet3D
     torch.manual_seed(0)
@@ -111,7 +111,8 @@ def train_step_line(device, steps=5):
 
     out = {"workload": "BASELINE configs[4]: Unet3D(dim=128,dim_mults=(1,2,4,8),channels=3) l1 loss forward + backward on "
                        "x=(1,3,16,128,128), bf16 autocast, random-init weights, no optimizer step", "steps": steps}
-    for key, backend in (("hip_ms", "hip"), ("torch_ops_ms", "torch-autograd")):
+    legs = (("hip_ms", "hip"),) + ((("torch_ops_ms", "torch-autograd"),) if torch_leg else ())
+    for key, backend in legs:
         for _ in range(2):
             step(backend)
         torch.cuda.synchronize()
@@ -121,6 +122,12 @@ def train_step_line(device, steps=5):
         torch.cuda.synchronize()
         out[key] = round((time.perf_counter() - t0) / steps * 1e3, 2)
     out["samples_per_s"] = round(1e3 / out["hip_ms"], 2)
+    # Algorithmic work of the step: the forward of this model on this clip is 3 324.7 GFLOP (counted on the reference
+    # with torch's FlopCounterMode), the backward twice that (input and weight gradients).  Against the dense bf16 peak.
+    gflop = 3.0 * 3324.7
+    tf = gflop / out["hip_ms"]
+    out["roofline"] = {"bound": "mfma", "algorithmic_gflop_per_step": round(gflop, 1), "achieved": round(tf, 1),
+                       "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
     return out
 
 
@@ -176,6 +183,7 @@ def main():
     ap.add_argument("--no-full-loop", action="store_true", help="skip the real 1000-step loop after the timed steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the configs[4] training-step line")
+    ap.add_argument("--train-torch-ops", action="store_true", help="also time the training step as torch ops (MIOpen convolutions)")
     ap.add_argument("--parts", type=int, default=None,
                     help="concurrent sub-batches one forward is run as (default: the library's choice)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
@@ -235,12 +243,16 @@ def main():
         plan.run()
         gd.ddpm_step(plan.x_in, plan.eps_out, plan.t_in, noise=None, clip_denoised=True, out=plan.x_in, rng_state=rng)
 
+    plan.t_in.fill_(TIMESTEPS - 1)
+
     def step(i):
-        plan.t_in.fill_(TIMESTEPS - 1 - (i % TIMESTEPS))
         if args.no_graph:
+            plan.t_in.fill_(TIMESTEPS - 1 - (i % TIMESTEPS))
             eager_step()
         else:
-            graph.replay()
+            if not getattr(plan, "self_advancing", False):
+                plan.t_in.fill_(TIMESTEPS - 1 - (i % TIMESTEPS))
+            graph.replay()          # the captured posterior kernel counts t down itself (wrapping after 0)
 
     for i in range(args.warmup):
         step(i)
@@ -444,7 +456,7 @@ def main():
         }
         if world == 1 and not args.no_train_step:
             try:
-                out["train_step"] = train_step_line(device)
+                out["train_step"] = train_step_line(device, torch_leg=args.train_torch_ops)
             except Exception as e:      # a side measurement: report the failure, keep the sampling line
                 out["train_step"] = {"failed": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1 and not args.no_cpu_baseline:

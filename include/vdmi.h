@@ -383,6 +383,14 @@ int vdmi_ddpm_step(const float* x, const float* eps, const float* z, const int64
 int vdmi_ddpm_step_rng(const float* x, const float* eps, const int64_t* t, const vdmi_ddpm_coefs* coefs,
                        float* out, int b, int64_t per_sample, int clip, const uint64_t* rng_state, vdmi_stream stream);
 
+/* vdmi_ddpm_step_rng for a loop replayed from a captured HIP graph (p_sample_loop, vdp.py:1004-1014: t runs from
+ * T - 1 down to 0): after the step, the workgroup that finishes last replaces every t[i] by t[i] - 1, or by
+ * timesteps - 1 when t[i] was 0, so the host never writes t between replays.  done_counter: one uint32 in device
+ * memory, zero before the first call (the kernel leaves it at zero). */
+int vdmi_ddpm_step_loop(const float* x, const float* eps, int64_t* t, const vdmi_ddpm_coefs* coefs, float* out, int b,
+                        int64_t per_sample, int clip, const uint64_t* rng_state, uint32_t* done_counter, int timesteps,
+                        vdmi_stream stream);
+
 /* Dynamic thresholding of the predicted x0 (vdp.py:957-968, 987-997; use_dynamic_thres of GaussianDiffusion):
  *   thres[i] = max(1, torch.quantile(|x0_i|, percentile))   over the per_sample elements of sample i,
  * x0 = srac[t]*x - srmac[t]*eps as in vdmi_ddpm_step, the quantile with torch's linear interpolation between the
@@ -485,6 +493,11 @@ int vdmi_layernorm_rows_bwd(const void* x, const void* dxh, const void* add, voi
  * attention over the positions of a frame (vdp.py:708-710; b = frames, f = positions, no rotary, no bias).
  * Backward: from qkv, o, lse and dout (gradient of o) the gradient of the raw qkv rows (dqkv, same layout) and of the
  * bias (dbias float [heads][f][f], ACCUMULATED; may be NULL). */
+/* HOST. 1 when vdmi_tattn_core_fwd (bwd = 0) / vdmi_tattn_core_bwd (bwd = 1; with_dbias: a relative-position-bias
+ * gradient is asked for) can run a token axis of f positions with `heads` heads: the site's tiles and, in the
+ * backward, the bias-gradient table [heads][f][f] must fit 160 KiB of LDS (with 8 heads the backward ends near
+ * f = 62), and f <= 256.  Callers fall back to torch ops for longer axes. */
+int vdmi_tattn_core_fits(int bwd, int f, int heads, int with_dbias);
 int vdmi_tattn_core_fwd(const void* qkv, void* o, float* lse, const float* bias, const float* rot_cos,
                         const float* rot_sin, int b, int f, int hw, int heads, float scale, vdmi_stream stream);
 int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* dbias,

@@ -229,3 +229,12 @@ def test_attention_training_entry_points_reject_bad_arguments():
     assert lib.vdmi_sla_train_rows_fwd(16, None, 16, 16, 2, 100, 4, 0.17, None) == E_ARG
     assert lib.vdmi_sla_train_rows_bwd(16, 16, 16, 16, None, 16, 2, 100, 4, 0.17, None) == E_ARG
     assert lib.vdmi_sla_train_rows_fwd(16, 16, 16, 16, 2, 100, 3, 0.17, None) == E_SHAPE
+
+
+def test_attention_core_fit_query():
+    """vdmi_tattn_core_fits (host): with 8 heads the backward core with a bias gradient holds token axes up to about
+    62 positions (its [heads][f][f] table and four tiles must fit 160 KiB of LDS); nothing beyond 256."""
+    lib = _lib.lib()
+    assert lib.vdmi_tattn_core_fits(1, 10, 8, 1) == 1 and lib.vdmi_tattn_core_fits(1, 32, 8, 1) == 1
+    assert lib.vdmi_tattn_core_fits(1, 64, 8, 1) == 0 and lib.vdmi_tattn_core_fits(0, 64, 8, 0) == 1
+    assert lib.vdmi_tattn_core_fits(0, 257, 8, 0) == 0 and lib.vdmi_tattn_core_fits(1, 0, 8, 0) == 0

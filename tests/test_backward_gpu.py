@@ -599,3 +599,34 @@ def test_fixed_weights_store_follows_the_version_counter():
         assert torch.equal(p1.data.float(), (p0.data.float() * 2.0))
     assert T._PACKS is None
     assert T.param_pack(w, False) is not p1                 # outside a block nothing is kept
+
+
+def test_long_frame_axis_falls_back_to_torch_ops_under_the_hip_backend():
+    """64 frames with 8 heads and a relative position bias: the backward attention core would need its [8][64][64]
+    bias-gradient table plus four tiles in LDS (> 160 KiB), so the "hip" backend's dispatcher (autograd._temporal)
+    takes the torch ops for this layer instead of failing in loss.backward() (reference layer: vdp.py:546-612, 636)."""
+    from video_diffusion_amd import autograd as A, train_hip as T
+    from video_diffusion_amd.modules import Attention, EinopsToAndFrom, PreNorm, Residual, RotaryEmbedding
+    assert T.attention_core_fits(32, 8, True) and not T.attention_core_fits(64, 8, True)
+    assert not T.attention_core_fits(300, 8, False)
+    torch.manual_seed(3)
+    c, f = 64, 64
+    rot = RotaryEmbedding(32)
+    res = Residual(PreNorm(c, EinopsToAndFrom('b c f h w', 'b (h w) f c', Attention(c, heads=8, dim_head=32, rotary_emb=rot)))).to(DEV)
+    x = torch.randn(1, c, f, 4, 4, device=DEV)
+    bias = (0.3 * torch.randn(8, f, f, device=DEV))
+
+    def run(hip_flag):
+        old = A._HIP_ATTN
+        A._HIP_ATTN = hip_flag
+        try:
+            xr = x.clone().requires_grad_(True)
+            br = bias.clone().requires_grad_(True)
+            out = A._temporal(res, xr, br)
+            out.square().mean().backward()
+            return out.detach(), xr.grad.clone(), br.grad.clone()
+        finally:
+            A._HIP_ATTN = old
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)          # the same torch ops ran both times

@@ -5,6 +5,8 @@ Reference arithmetic: video_diffusion_pytorch/video_diffusion_pytorch.py:731-754
 :756-831 (Unet3D.forward), :973-1014 (p_sample / p_sample_loop) of the reference.  Tolerance: BASELINE.json's bf16 bar,
 2e-2 relative L2 error per epsilon prediction; the full-loop bound is stated at its test.
 """
+import os
+
 import pytest
 import torch
 
@@ -282,3 +284,49 @@ def test_sla_pass1_beside_fold_kernels_on_another_stream():
         main.wait_stream(s1)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(ws, ref)), it
+
+
+def test_cfg4_loss_and_gradients_vs_reference():
+    """configs[4] at full size on the HIP training kernels: one L1-loss forward + backward of Unet3D(dim=128,
+    channels=3) on a (1, 3, 16, 128, 128) clip (the denoiser call and loss of p_losses, reference vdp.py:1146-1161, and
+    its backward, :1451) against the reference's own fp32 loss and gradients (tests/golden/cfg4_grads.npz, made by
+    oracle/make_golden_cfg4_grads.py from the imported reference).  Compared: the loss, the L2 norm of every
+    parameter's gradient, and the leading 256 entries of the gradient of a few layers of every kind; the set of
+    parameters the step does not reach must be the reference's (the cross-attention layers)."""
+    import torch.nn.functional as F
+    if PRECISION != "bf16":
+        pytest.skip("the training kernels are built for the bf16 library")
+    g = golden("cfg4_grads")
+    names = open(os.path.join(os.path.dirname(__file__), "golden", "cfg4_grads_names.txt")).read().split()
+    m = make_unet(**CFG4).to(dev())
+    m.train()
+    m.train_backend = "hip"
+    x = inp("cfg4.x", (1, 3, 16, 128, 128)).to(dev())
+    target = inp("cfg4.noise", (1, 3, 16, 128, 128)).to(dev())
+    loss = F.l1_loss(m(x, g["t"].to(dev())).float(), target)
+    loss.backward()
+    e_loss = abs(float(loss.detach()) - float(g["loss"][0])) / float(g["loss"][0])
+    assert record("cfg4_train_loss", e_loss, 1e-2) < 1e-2
+    params = dict(m.named_parameters())
+    ref_norms = dict(zip(names, g["grad_norms"].tolist()))
+    worst, worst_name = 0.0, None
+    for n, rn in ref_norms.items():
+        gr = params[n].grad
+        if rn < 0:
+            assert gr is None or float(gr.abs().max()) == 0.0, n          # the reference's step does not reach it either
+            continue
+        assert gr is not None, n
+        e = abs(float(gr.double().norm()) - rn) / max(rn, 1e-12)
+        if e > worst:
+            worst, worst_name = e, n
+    record("cfg4_train_grad_norm_worst_parameter", worst, 2e-2)
+    assert worst < 2e-2, (worst_name, worst)
+    errs = []
+    for k, v in g.items():
+        if k.startswith("slice."):
+            got = params[k[len("slice."):]].grad.reshape(-1)[:256].float().cpu()
+            errs.append((rel_err(got, v.float()), k))
+    record("cfg4_train_grad_slices_worst", max(errs)[0], 1.5e-1)
+    record("cfg4_train_grad_slices_median", sorted(errs)[len(errs) // 2][0], 3e-2)
+    assert max(errs)[0] < 1.5e-1, max(errs)
+    assert sorted(errs)[len(errs) // 2][0] < 3e-2

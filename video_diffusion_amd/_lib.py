@@ -139,6 +139,8 @@ _SIGNATURES = {
                                         C.c_int, C.c_void_p]),
     "vdmi_ddpm_step_rng": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p, C.c_int,
                                      C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "vdmi_ddpm_step_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p, C.c_int,
+                                      C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vdmi_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs),
                                  C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vdmi_dynamic_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p, C.c_int,
@@ -161,6 +163,7 @@ _SIGNATURES = {
     "vdmi_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "vdmi_layernorm_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "vdmi_layernorm_rows_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    "vdmi_tattn_core_fits": (C.c_int, [C.c_int] * 4),
     "vdmi_tattn_core_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "vdmi_tattn_core_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "vdmi_sla_train_partial_bytes": (C.c_size_t, [C.c_int] * 3),

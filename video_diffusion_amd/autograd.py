@@ -130,11 +130,18 @@ def _rot_tables(rot, nf, device):
     return hit[1]
 
 
+def _core_fits(n_tok, heads, with_bias):
+    """The HIP attention cores keep a site's tiles (and the backward's bias-gradient table) in LDS: long token axes
+    (from about 63 frames with 8 heads and a relative position bias) stay on torch ops."""
+    from .train_hip import attention_core_fits
+    return attention_core_fits(int(n_tok), int(heads), bool(with_bias))
+
+
 def _temporal(res, x, pos_bias, focus=None):
     # Residual(PreNorm(EinopsToAndFrom('b c f h w', 'b (h w) f c', Attention))), vdp.py:636
-    if _HIP_ATTN and focus is None and x.is_cuda:
+    att = res.fn.fn.fn
+    if _HIP_ATTN and focus is None and x.is_cuda and _core_fits(x.shape[2], att.heads, pos_bias is not None):
         from .train_hip import temporal_attention     # forward and backward on the HIP kernels
-        att = res.fn.fn.fn
         return temporal_attention(res, x, pos_bias, _rot_tables(getattr(att, "rotary_emb", None), x.shape[2], x.device))
     return _torch_ops(lambda x: _temporal_ops(res, x, pos_bias, focus), x)
 
@@ -148,7 +155,8 @@ def _temporal_ops(res, x, pos_bias, focus):
 
 def _spatial(res, x):
     # mid_spatial_attn: 'b c f h w -> b f (h w) c', vdp.py:708-710
-    if _HIP_ATTN and x.is_cuda and x.shape[3] * x.shape[4] <= 256:
+    if _HIP_ATTN and x.is_cuda and x.shape[3] * x.shape[4] <= 256 and \
+            _core_fits(x.shape[3] * x.shape[4], res.fn.fn.fn.heads, False):
         from .train_hip import spatial_attention      # forward and backward on the HIP kernels
         return spatial_attention(res, x)
     return _torch_ops(lambda x: _spatial_ops(res, x), x)
@@ -261,11 +269,10 @@ def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null
     bias = _pos_bias(unet, x.shape[2], device)
 
     if _HIP_RESNET and x.is_cuda:
-        from .train_hip import init_conv        # torch forward, weight gradient on the HIP kernels
-        x = init_conv(unet.init_conv, x)
-        if _HIP_ATTN:
-            # from here to final_conv the activations stay bf16: every HIP layer hands a view of its output rows to the next
-            x = x.to(torch.bfloat16)
+        from .train_hip import init_conv        # forward and weight gradient on the HIP kernels
+        # with the attention layers on the library too, the activations stay bf16 from here to final_conv: every HIP
+        # layer hands a view of its output rows to the next
+        x = init_conv(unet.init_conv, x, torch.bfloat16 if _HIP_ATTN else torch.float32)
     else:
         x = unet.init_conv(x)
     x = _temporal(unet.init_temporal_attn, x, bias)

@@ -328,22 +328,30 @@ size_t core_lds_bytes(bool bwd, int f, int hpw, int spw, int bias_heads) {
     return bwd ? 4 * tile + (size_t)2 * spw * f * hpw * 4 + (size_t)bias_heads * f * f * 4 : 2 * tile;
 }
 
+// The most heads per pass (a divisor of heads) and sites per pass that 256 threads and the LDS hold; false when no
+// split fits (long token axes: the tiles and, in the backward, the bias-gradient table [heads][f][f] live in LDS).
+bool core_split(bool bwd, int f, int heads, bool with_dbias, int* hpw_out, int* spw_out, size_t* lds_out) {
+    if (f <= 0 || f > 256 || heads <= 0) return false;
+    const int bias_heads = (bwd && with_dbias) ? heads : 0;
+    for (int hp = heads; hp >= 1; --hp) {
+        if (heads % hp || f * hp > 256) continue;
+        for (int sp = 256 / (f * hp); sp >= 1; --sp)
+            if (core_lds_bytes(bwd, f, hp, sp, bias_heads) <= 160 * 1024) {
+                if (hpw_out) *hpw_out = hp;
+                if (spw_out) *spw_out = sp;
+                if (lds_out) *lds_out = core_lds_bytes(bwd, f, hp, sp, bias_heads);
+                return true;
+            }
+    }
+    return false;
+}
+
 int core_launch(bool bwd, CoreArgs& a, hipStream_t stream) {
     if (a.b <= 0 || a.f <= 0 || a.f > 256 || a.hw <= 0 || a.heads <= 0) return VDMI_E_SHAPE;
     if ((a.rot_cos == nullptr) != (a.rot_sin == nullptr)) return VDMI_E_ARG;
-    // the most heads per pass (a divisor of heads) and sites per pass that 256 threads and the LDS hold
-    const int bias_heads = (bwd && a.dbias) ? a.heads : 0;
     int hpw = 0, spw = 0;
     size_t lds = 0;
-    for (int hp = a.heads; hp >= 1 && !hpw; --hp) {
-        if (a.heads % hp || a.f * hp > 256) continue;
-        for (int sp = 256 / (a.f * hp); sp >= 1; --sp)
-            if (core_lds_bytes(bwd, a.f, hp, sp, bias_heads) <= 160 * 1024) {
-                hpw = hp; spw = sp; lds = core_lds_bytes(bwd, a.f, hp, sp, bias_heads);
-                break;
-            }
-    }
-    if (!hpw) return VDMI_E_LDS;
+    if (!core_split(bwd, a.f, a.heads, a.dbias != nullptr, &hpw, &spw, &lds)) return VDMI_E_LDS;
     a.spw = spw;
     a.hpw = hpw;
     a.hgroups = a.heads / hpw;
@@ -372,6 +380,10 @@ int ln_check(const void* x, const void* out, int64_t rows, int c) {
 }
 
 }   // namespace
+
+extern "C" int vdmi_tattn_core_fits(int bwd, int f, int heads, int with_dbias) {
+    return core_split(bwd != 0, f, heads, with_dbias != 0, nullptr, nullptr, nullptr) ? 1 : 0;
+}
 
 extern "C" int vdmi_layernorm_rows(const void* x, void* xh, int64_t rows, int c, float eps, vdmi_stream stream) {
     const int st = ln_check(x, xh, rows, c);

@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
                                                         vdmi_ddpm_coefs cf, float* __restrict__ out, long long per_sample,
                                                         long long groups_per_sample, int clip, uint64_t seed,
                                                         uint64_t offset, const uint64_t* __restrict__ rng,
-                                                        const float* __restrict__ thres) {
+                                                        const float* __restrict__ thres, long long* t_next,
+                                                        unsigned* done, int t_wrap) {
     // rng != null: key and counter offset live in device memory (a captured graph then draws what the buffer says)
     if (rng) { seed = rng[0]; offset = rng[1]; }
     const int b = blockIdx.y;
@@ -529,6 +530,22 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (e < cnt) out[base + i0 + e] = ov[e];
+        }
+    }
+    // Loop form: the workgroup that finishes last moves every sample's timestep on to t - 1 (wrapping to t_wrap - 1
+    // below zero), so a captured step can be replayed without the host touching t.  Every workgroup has read its t
+    // before it counts itself done, and the counter is back at zero for the next launch.
+    if (t_next) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned total = gridDim.x * gridDim.y;
+            if (atomicAdd(done, 1u) == total - 1) {
+                *done = 0;
+                for (unsigned i = 0; i < gridDim.y; ++i) {
+                    const long long v = t_next[i];
+                    t_next[i] = v > 0 ? v - 1 : t_wrap - 1;
+                }
+            }
         }
     }
 }
@@ -633,7 +650,8 @@ extern "C" int vdmi_block_scale_shift(const float* emb_silu, int b, int emb_dim,
 static int ddpm_step_launch(const float* x, const float* eps, const float* z, const int64_t* t,
                             const vdmi_ddpm_coefs* coefs, float* out, int b, int64_t per_sample, int clip,
                             uint64_t seed, uint64_t offset, const uint64_t* rng, vdmi_stream stream,
-                            const float* thres = nullptr) {
+                            const float* thres = nullptr, long long* t_next = nullptr, unsigned* done = nullptr,
+                            int t_wrap = 0) {
     if (!x || !eps || !t || !coefs || !out) return VDMI_E_ARG;
     if (!coefs->sqrt_recip_alphas_cumprod || !coefs->sqrt_recipm1_alphas_cumprod || !coefs->posterior_mean_coef1 ||
         !coefs->posterior_mean_coef2 || !coefs->posterior_log_variance_clipped)
@@ -646,7 +664,7 @@ static int ddpm_step_launch(const float* x, const float* eps, const float* z, co
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)bx, (unsigned)b), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, eps, z, t, *coefs, out, (long long)per_sample, groups, clip,
-                       seed, offset, rng, thres);
+                       seed, offset, rng, thres, t_next, done, t_wrap);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
@@ -662,6 +680,14 @@ extern "C" int vdmi_ddpm_step_rng(const float* x, const float* eps, const int64_
                                   vdmi_stream stream) {
     if (!rng_state || (reinterpret_cast<uintptr_t>(rng_state) & 7u)) return VDMI_E_ARG;
     return ddpm_step_launch(x, eps, nullptr, t, coefs, out, b, per_sample, clip, 0, 0, rng_state, stream);
+}
+
+extern "C" int vdmi_ddpm_step_loop(const float* x, const float* eps, int64_t* t, const vdmi_ddpm_coefs* coefs, float* out,
+                                   int b, int64_t per_sample, int clip, const uint64_t* rng_state, uint32_t* done_counter,
+                                   int timesteps, vdmi_stream stream) {
+    if (!rng_state || (reinterpret_cast<uintptr_t>(rng_state) & 7u) || !done_counter || timesteps <= 0) return VDMI_E_ARG;
+    return ddpm_step_launch(x, eps, nullptr, t, coefs, out, b, per_sample, clip, 0, 0, rng_state, stream, nullptr,
+                            reinterpret_cast<long long*>(t), done_counter, timesteps);
 }
 
 extern "C" int vdmi_dynamic_threshold(const float* x, const float* eps, const int64_t* t, const vdmi_ddpm_coefs* coefs,

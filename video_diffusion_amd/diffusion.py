@@ -158,9 +158,12 @@ class GaussianDiffusion(nn.Module):
         self._rng_state(device).copy_(torch.tensor([seed, 0], dtype=torch.int64))
         return seed
 
-    def ddpm_step(self, x, eps, t, noise=None, clip_denoised=True, out=None, seed=0, offset=0, rng_state=None):
+    def ddpm_step(self, x, eps, t, noise=None, clip_denoised=True, out=None, seed=0, offset=0, rng_state=None,
+                  advance_t=None):
         """x_{t-1} from (x_t, eps, noise) in one HIP kernel.  noise=None draws Philox noise in-kernel, keyed by
-        (seed, offset) or, when rng_state (device int64 [2]) is given, by the two words it holds."""
+        (seed, offset) or, when rng_state (device int64 [2]) is given, by the two words it holds.
+        advance_t (device int32 [1], zero; needs rng_state and the static clip): the kernel also moves t on to t - 1
+        (num_timesteps - 1 after 0), for captured steps that are replayed without the host writing t."""
         if not x.is_cuda:
             raise _lib.VdmiError("ddpm_step runs on the HIP device only")
         x = x.contiguous()
@@ -181,6 +184,12 @@ class GaussianDiffusion(nn.Module):
                 x.data_ptr(), eps.data_ptr(), None if noise is None else noise.contiguous().data_ptr(), t.data_ptr(),
                 C.byref(self._coefs()), thres.data_ptr(), out.data_ptr(), b, x.numel() // b,
                 None if noise is not None else rng_state.data_ptr(), stream), "vdmi_ddpm_step_thres")
+            return out
+        if noise is None and rng_state is not None and advance_t is not None:
+            check(_lib.lib().vdmi_ddpm_step_loop(
+                x.data_ptr(), eps.data_ptr(), t.data_ptr(), C.byref(self._coefs()), out.data_ptr(), b, x.numel() // b,
+                int(bool(clip_denoised)), rng_state.data_ptr(), advance_t.data_ptr(), int(self.num_timesteps),
+                torch.cuda.current_stream().cuda_stream), "vdmi_ddpm_step_loop")
             return out
         if noise is None and rng_state is not None:
             check(_lib.lib().vdmi_ddpm_step_rng(
@@ -229,17 +238,22 @@ class GaussianDiffusion(nn.Module):
         plan = fn.engine().plan(B, Fr, H, W, device, time_table=self.num_timesteps)
         z = torch.zeros(shape, device=device, dtype=torch.float32) if self.noise_source == "torch" else None
         rng = self._rng_state(device)       # read by the captured kernel at every replay: the loop rewrites it per call
+        # with in-kernel noise and the static clip the posterior kernel also counts t down: the loop sets t once
+        self_advancing = z is None and not self.use_dynamic_thres
+        tcount = torch.zeros(1, device=device, dtype=torch.int32) if self_advancing else None
 
         def step():
             plan.run()
             if z is not None:
                 z.normal_()
-            self.ddpm_step(plan.x_in, plan.eps_out, plan.t_in, noise=z, clip_denoised=True, out=plan.x_in, rng_state=rng)
+            self.ddpm_step(plan.x_in, plan.eps_out, plan.t_in, noise=z, clip_denoised=True, out=plan.x_in, rng_state=rng,
+                           advance_t=tcount)
 
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             saved = plan.x_in.clone()
+            plan.t_in.fill_(0)
             step()                      # warm-up outside capture (sets kernel attributes, allocates)
             plan.x_in.copy_(saved)
         torch.cuda.current_stream(device).wait_stream(side)
@@ -247,6 +261,8 @@ class GaussianDiffusion(nn.Module):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step()
+        plan.self_advancing = self_advancing
+        plan.step_counter = tcount          # the captured kernel counts in it at every replay: it lives as long as the plan
         runner = (graph, plan)
         self._graphs[key] = runner
         return runner
@@ -273,9 +289,11 @@ class GaussianDiffusion(nn.Module):
         if runner is not None:
             graph, plan = runner
             plan.x_in.copy_(img)
+            plan.t_in.fill_(self.num_timesteps - 1)
             for i in reversed(range(0, self.num_timesteps)):
-                plan.t_in.fill_(i)
-                graph.replay()
+                if not plan.self_advancing:
+                    plan.t_in.fill_(i)
+                graph.replay()      # (a self-advancing step leaves t at i - 1 for the next replay)
             return plan.x_in.clone()
         for k, i in enumerate(reversed(range(0, self.num_timesteps))):
             t = torch.full((b,), i, device=device, dtype=torch.long)

@@ -317,15 +317,26 @@ class ResnetBlockFn(torch.autograd.Function):
 
 
 class InitConvFn(torch.autograd.Function):
-    """Unet3D.init_conv (vdp.py:644, 772): torch's forward, the weight gradient on vdmi_conv_wgrad_gather (the library
-    convolution torch falls back to for a 3-channel (1,7,7) weight gradient takes 40 ms at 16 x 128 x 128)."""
+    """Unet3D.init_conv (vdp.py:644, 772).  Forward on vdmi_init_conv (the sampling plan's kernel: float channels-first
+    in, bf16 rows out, products in split-bf16 = float precision); the weight gradient on vdmi_conv_wgrad_gather (the
+    library convolutions torch falls back to for this 3-channel (1,7,7) layer take 20 ms forward and 40 ms for the weight
+    gradient at 16 x 128 x 128).  `act`: dtype of the result (bfloat16: a view of the output rows)."""
 
     @staticmethod
     @_plain
-    def forward(ctx, x, weight, bias, pad):
+    def forward(ctx, x, weight, bias, pad, act):
         ctx.save_for_backward(x, weight)
         ctx.pad = pad
-        return F.conv3d(x.float(), weight, bias, padding=(0, pad, pad))
+        b, cin, f, h, w = x.shape
+        cout, k = weight.shape[0], weight.shape[3]
+        if not (x.is_cuda and cout % 16 == 0 and k == 2 * pad + 1):
+            return F.conv3d(x.float(), weight, bias, padding=(0, pad, pad)).to(act)
+        rows = torch.empty(b * f * h * w, cout, device=x.device, dtype=torch.bfloat16)
+        w2 = weight.detach()[:, :, 0].float().contiguous()
+        bz = bias.detach().float().contiguous() if bias is not None else torch.zeros(cout, device=x.device)
+        check(_lib.lib().vdmi_init_conv(x.detach().float().contiguous().data_ptr(), w2.data_ptr(), bz.data_ptr(),
+                                        rows.data_ptr(), b, cin, f, h, w, cout, k, _stream()), "vdmi_init_conv")
+        return from_rows(rows, b, f, h, w, act)
 
     @staticmethod
     @_plain
@@ -340,15 +351,16 @@ class InitConvFn(torch.autograd.Function):
         xr = torch.zeros(b * f * h * w, cpad, device=x.device, dtype=torch.bfloat16)
         xr[:, :cin] = x.permute(0, 2, 3, 4, 1).reshape(-1, cin)
         # the transposed layout is channel-major: the padding channels are simply never addressed
-        dw = conv_wgrad_gather(rows_transposed(xr, b * f, h * w), rows_transposed(to_rows(dout), b * f, h * w),
+        do_rows = to_rows(dout)
+        dw = conv_wgrad_gather(rows_transposed(xr, b * f, h * w), rows_transposed(do_rows, b * f, h * w),
                                cin, cout, b * f, h, w, kh, kw)
-        return dx, dw, dout.float().sum(dim=(0, 2, 3, 4)), None
+        return dx, dw, dout.float().sum(dim=(0, 2, 3, 4)), None, None
 
 
-def init_conv(conv: torch.nn.Conv3d, x: torch.Tensor) -> torch.Tensor:
+def init_conv(conv: torch.nn.Conv3d, x: torch.Tensor, act=torch.float32) -> torch.Tensor:
     kh, kw = conv.kernel_size[1], conv.kernel_size[2]
     assert conv.kernel_size[0] == 1 and kh == kw and conv.padding == (0, kh // 2, kw // 2)
-    return InitConvFn.apply(x, conv.weight, conv.bias, kh // 2)
+    return InitConvFn.apply(x, conv.weight, conv.bias, kh // 2, act)
 
 
 class PointwiseConvFn(torch.autograd.Function):
@@ -361,6 +373,16 @@ class PointwiseConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         w2 = weight.reshape(weight.shape[0], weight.shape[1])
+        b, cin, f, h, w = x.shape
+        cout = w2.shape[0]
+        if x.is_cuda and x.dtype == torch.bfloat16 and cout <= 8 and cin % 8 == 0:
+            # a bf16 activation stream ("hip" backend): the sampling plan's kernel, bf16 rows in (a view of the previous
+            # layer's output), float channels-first out; a float input keeps the float matmul (nothing is rounded)
+            out = torch.empty(b, cout, f, h, w, device=x.device, dtype=torch.float32)
+            check(_lib.lib().vdmi_final_conv(to_rows(x).data_ptr(), w2.detach().float().contiguous().data_ptr(),
+                                             bias.detach().float().contiguous().data_ptr(), out.data_ptr(), b, cin, f, h, w,
+                                             cout, _stream()), "vdmi_final_conv")
+            return out
         return torch.einsum("oc,bcfhw->bofhw", w2, x.float()) + bias.view(1, -1, 1, 1, 1)
 
     @staticmethod
@@ -508,6 +530,14 @@ class TemporalAttnFn(torch.autograd.Function):
         check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
                                           _stream()), "vdmi_layernorm_rows_bwd")
         return from_rows(dx, b, f, h, w, ctx.act), dgamma, dwqkv, dwout, dbias, None, None, None, None, None, None
+
+
+def attention_core_fits(n_tok: int, heads: int, with_bias: bool) -> bool:
+    """Whether the attention core kernels (forward AND backward, the latter with the bias-gradient table [heads][n][n] in
+    LDS when the layer has a relative position bias) take a token axis of n_tok positions: 8 heads with a bias end near
+    62 frames.  The dispatchers in autograd.py fall back to torch ops beyond it."""
+    lib = _lib.lib()
+    return bool(lib.vdmi_tattn_core_fits(0, n_tok, heads, 0)) and bool(lib.vdmi_tattn_core_fits(1, n_tok, heads, int(with_bias)))
 
 
 def spatial_attention(res, x: torch.Tensor) -> torch.Tensor:

@@ -309,10 +309,18 @@ class Trainer(object):
                 from . import train_hip
                 backend = "hip" if (dev.type == "cuda" and train_hip.supports(self.model.denoise_fn)) else "torch-autograd"
             self.model.denoise_fn.train_backend = backend
-        loss_mod = _LossModule(self.model, self.null_frame_cond_prob)
+        loss_core = _LossModule(self.model, self.null_frame_cond_prob)
+        loss_mod = loss_core
+        ddp_kw = dict(device_ids=[dev.index] if dev.type == "cuda" else None)
+        unused_names = None             # distributed: parameters no step reaches, found in the first step
         if self.distributed:
-            loss_mod = nn.parallel.DistributedDataParallel(
-                loss_mod, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=True)
+            # Which parameters a step reaches is fixed by the Trainer's configuration (the cross-attention layers of a model
+            # trained without previous frames, the null condition embedding of a model without a condition): the masks
+            # drawn per step multiply tensors, they never remove a layer from the graph.  So the first step runs with
+            # DDP's search for unused parameters; what it leaves without a gradient is then excluded from the reducer and
+            # every later step runs without the walk over the autograd graph (checked per step: an excluded parameter
+            # that does receive a gradient raises).
+            loss_mod = nn.parallel.DistributedDataParallel(loss_core, find_unused_parameters=True, **ddp_kw)
 
         while self.step < self.train_num_steps:
             for i in range(self.gradient_accumulate_every):
@@ -326,6 +334,18 @@ class Trainer(object):
                                                                         focus_present_mask)
                     self.scaler.scale(total_loss / self.gradient_accumulate_every).backward()
             log = {'loss': diffusion_loss.item(), 'vae_loss': vae_loss.item()}
+
+            if self.distributed:
+                named = [(n, p) for n, p in loss_core.named_parameters() if p.requires_grad]
+                if unused_names is None:
+                    unused_names = [n for n, p in named if p.grad is None]
+                    nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(loss_core, unused_names)
+                    loss_mod = nn.parallel.DistributedDataParallel(loss_core, find_unused_parameters=False, **ddp_kw)
+                else:
+                    late = [n for n, p in named if n in unused_set and p.grad is not None]
+                    if late:
+                        raise RuntimeError(f"parameters excluded from gradient averaging received gradients: {late[:4]}")
+                unused_set = set(unused_names)
 
             if exists(self.max_grad_norm):
                 self.scaler.unscale_(self.opt)
