@@ -163,10 +163,11 @@ void vdmi_wsconv_enable(int on);
 int vdmi_wsconv_covers(const vdmi_tapgemm_args* a);
 
 /* HOST. vdmi_tapgemm runs the plain-epilogue (1,3,3) convolutions of 8-, 16- and 32-pixel-wide images with 64-channel
- * input chunks and a multiple of 128 output channels (tile_bn = 64: Block.proj of the wide layers, vdp.py:412-420)
+ * input chunks and a multiple of 128 output channels (tile_bn = 64: Block.proj of the wide layers, vdp.py:412-420),
+ * and the NORM_SILU convolutions with exactly 128 output channels on 32-pixel-wide images (Block, vdp.py:412-427),
  * on a streaming kernel (256-pixel x 128-channel tiles, patch and weights by LDS-DMA); 0 keeps them on the general
  * tap-GEMM (tests and A/B timing; the environment variable VDMI_DCONV=0 does the same for a process). */
-void vdmi_dconv_enable(int on);
+void vdmi_dconv_enable(int on);      /* 2: also the RMSNorm-epilogue form on every width it is built for (tests) */
 /* 1 when vdmi_tapgemm would run this launch on the streaming kernel, else 0. */
 int vdmi_dconv_covers(const vdmi_tapgemm_args* a);
 

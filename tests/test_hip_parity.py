@@ -1110,3 +1110,69 @@ def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, kspli
     assert rel_err(y_new, ref) < 4e-3 * max(1, ksplit) ** 0.5        # one bf16 rounding per partial sum
     assert rel_err(y_new, y_old) < 2e-3
     assert (y_new != y_old).float().mean() < 0.05
+
+
+@pytest.mark.parametrize("W,H,frames,fpb,c0,c1,with_res,with_shift", [
+    (32, 32, 4, 2, 128, 0, True, True),       # 8-row bands, identity residual (block2 of a ResnetBlock)
+    (16, 16, 6, 3, 64, 64, False, True),      # two sources, per-sample scale / shift (block1)
+    (8, 8, 10, 5, 256, 0, True, False),       # four stacked frames per tile spanning two samples
+    (32, 32, 2, 2, 64, 0, False, False),      # a single input chunk
+])
+def test_streaming_conv_with_norm_epilogue_matches_tapgemm_and_torch(W, H, frames, fpb, c0, c1, with_res, with_shift):
+    """The streaming conv with the Block epilogue (conv + bias, RMSNorm over the 128 output channels, * gain + shift,
+    SiLU, + identity residual: reference vdp.py:391-427, 452) against the tap-GEMM's fused epilogue on the same
+    arguments and against torch ops on the bf16-rounded operands."""
+    import ctypes as C
+    from video_diffusion_amd import _lib
+    from video_diffusion_amd.engine import PackedTaps, TAPS_3x3, _fill_pass
+    lib = _lib.lib()
+    n, cin, nb = 128, c0 + c1, frames // fpb
+    rows = frames * H * W
+    wt = inp(f"dconvn.w{W}.{cin}", (n, cin, 9), scale=(9 * cin) ** -0.5)
+    bias = inp("dconvn.b", (n,), scale=0.1).to(dev())
+    gain = (1.0 + 0.5 * inp(f"dconvn.g{nb}", (nb, n))).contiguous().to(dev())
+    shift = inp(f"dconvn.s{nb}", (nb, n)).contiguous().to(dev()) if with_shift else None
+    pk = PackedTaps(wt, c0, c1, _lib.EPI_NORM_SILU, dev())
+    x0 = inp(f"dconvn.x0.{W}.{c0}", (rows, c0)).to(ACT).to(dev())
+    x1 = inp(f"dconvn.x1.{W}.{c1}", (rows, c1)).to(ACT).to(dev()) if c1 else None
+    res = inp(f"dconvn.r{W}", (rows, n)).to(ACT).to(dev()) if with_res else None
+
+    def run(enable):
+        out = torch.full((rows, n), float("nan"), device=dev(), dtype=ACT)
+        a = _lib.TapGemmArgs()
+        a.frames, a.frames_per_batch = frames, fpb
+        a.grid_h, a.grid_w, a.out_h, a.out_w = H, W, H, W
+        a.out_mul = 1
+        a.out, a.ldo, a.n, a.epilogue = out.data_ptr(), n, n, _lib.EPI_NORM_SILU
+        _fill_pass(a.main, x0, c0, x1, c1, H, W, 1, TAPS_3x3, pk.data)
+        a.bias = bias.data_ptr()
+        a.gain, a.gain_bstride = gain.data_ptr(), n
+        if with_shift:
+            a.shift, a.shift_bstride = shift.data_ptr(), n
+        a.norm_scale = float(n) ** 0.5
+        if with_res:
+            a.has_res, a.res_identity, a.ld_res = 2, res.data_ptr(), n
+        lib.vdmi_dconv_enable(2 if enable else 0)       # 2: the norm epilogue on every width the kernel is built for
+        try:
+            assert lib.vdmi_dconv_covers(C.byref(a)) == (1 if enable else 0)
+            _lib.check(lib.vdmi_tapgemm(C.byref(a), torch.cuda.current_stream().cuda_stream), "vdmi_tapgemm")
+            torch.cuda.synchronize()
+        finally:
+            lib.vdmi_dconv_enable(1)
+        return out.float().cpu()
+
+    y_new, y_old = run(True), run(False)
+    assert torch.isfinite(y_new).all()
+    x = torch.cat([t.float().cpu() for t in (x0, x1) if t is not None], dim=1)
+    xi = x.reshape(frames, H, W, cin).permute(0, 3, 1, 2)
+    y = torch.nn.functional.conv2d(xi, wt.to(ACT).float().reshape(n, cin, 3, 3), bias.cpu(), padding=1)
+    y = y.permute(0, 2, 3, 1).reshape(rows, n)
+    b = torch.arange(rows) // (fpb * H * W)
+    y = torch.nn.functional.normalize(y, dim=1) * n ** 0.5 * gain.cpu()[b]
+    if with_shift:
+        y = y + shift.cpu()[b]
+    y = torch.nn.functional.silu(y)
+    if with_res:
+        y = y + res.float().cpu()
+    assert rel_err(y_new, y) < 4e-3
+    assert rel_err(y_new, y_old) < 2e-3

@@ -38,9 +38,28 @@ struct DcArgs {
     int npx, nnt, ksplit;           // pixel tiles, 128-channel tiles, shares of the contraction
     unsigned src0_bytes, src1_bytes, w_bytes;
     long long rows;                 // frames * H * W
+    // RMSNorm epilogue (n == 128: the tile holds every output channel of its pixels)
+    const float* gain;              // [B][gain_bs]: gamma * (scale + 1)
+    const float* shift;             // [B][shift_bs] or null
+    long long gain_bs, shift_bs;
+    const __bf16* res;              // identity residual rows [rows][ld_res] or null
+    int ld_res, fpb;                // frames per batch element
+    float norm_scale;
+    unsigned long long* diag;       // diagnostic builds only
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// Diagnostic builds only (-DVDMI_DIAG_STAMPS, never shipped): lane 0 of wave 0 of every workgroup records the cycle
+// counter at a few points into a buffer whose address comes from the VDMI_DIAG_PTR environment variable.
+#ifdef VDMI_DIAG_STAMPS
+#define DC_STAMP(slot)                                                                                 \
+    do {                                                                                               \
+        if (a.diag && threadIdx.x == 0) a.diag[(size_t)blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define DC_STAMP(slot) do { } while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -58,7 +77,9 @@ __device__ __forceinline__ void wait_vm() {
 
 // W: image width; R: image rows per sub-block of the tile (a whole 8x8 / 16x16 frame, or a band of a larger one);
 // the tile stacks NF = 256 / (R * W) sub-blocks.
-template <int W, int R>
+// NORM: bias, RMSNorm over the 128 output channels, * gain + shift, SiLU, + identity residual (Block.forward and the
+// ResnetBlock sum, reference vdp.py:391-427, 452) instead of the plain epilogue.
+template <int W, int R, bool NORM>
 __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
     constexpr int NF = 256 / (R * W), PW = W + 2, PR = R + 2, NPP = NF * PR * PW;
     constexpr int NPIECE = (NPP + 7) / 8, PBUF = NPIECE * 1024, NU = (NPIECE + 7) / 8;
@@ -68,6 +89,7 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
     static_assert(WOFF + RING * WSLOT <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    DC_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
@@ -203,8 +225,10 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
     for (int u = 0; u < NU; ++u) issue_patch_piece(0, u);
     issue_weights(0, 0);
     issue_weights(1, 1);
+    DC_STAMP(1);
     wait_vm<2>();                       // patch and tile 0 (tile 1 may still be on its way)
     __builtin_amdgcn_s_barrier();
+    DC_STAMP(2);
     {
         int ab[2], xv[2];
         tap_addr(0, ab, xv);
@@ -248,10 +272,13 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
             slot = slot1;
         }
     }
+    DC_STAMP(3);
     wait_vm<0>();                       // the out-of-range requests of the last steps still write (zeros) into LDS
     __builtin_amdgcn_s_barrier();
+    DC_STAMP(4);
 
-    // ---- epilogue: + bias (share 0), bf16, transposed through LDS so that 8 lanes store one pixel's 128 contiguous bytes
+    // ---- epilogue: + bias (share 0) [NORM: RMSNorm, gain / shift, SiLU, residual], bf16, transposed through LDS so that
+    // 8 lanes store one pixel's 128 contiguous bytes
     const int n0 = nt * 128 + wn * 64;
     if (a.bias && ksp == 0) {
 #pragma unroll
@@ -266,21 +293,87 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
             }
     }
     constexpr int SROW = 64 + 8;
+    constexpr int RED_OFF = 8 * 64 * SROW * 2;          // behind the staging regions: [2 channel groups][256 pixels] floats
     __bf16* stg = reinterpret_cast<__bf16*>(smem) + wave * 64 * SROW;
+    const int srow0 = lane >> 3, schunk = lane & 7;
+    const long long row0 = (long long)tile * 256 + wm * 64;
+    if constexpr (NORM) {
+        // sum of squares over this wave's 64 channels; the wave with the other 64 channels of the same pixels is wave ^ 4
+        float ss[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v = fmaf(acc[i][j][r], acc[i][j][r], v);
+            ss[j] = xhalf_add(v);
+        }
+        float* red = reinterpret_cast<float*>(smem + RED_OFF);
+        if (lane < 32) {
+            red[wn * 256 + wm * 64 + l31] = ss[0];
+            red[wn * 256 + wm * 64 + 32 + l31] = ss[1];
+        }
+        // identity residual: fetched with the coalesced pattern of the stores below, added in fp32 further down
+        if (a.res) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = k * 8 + srow0;
+                bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (row0 + row < a.rows) rv = *reinterpret_cast<const bf16x8*>(a.res + (row0 + row) * a.ld_res + n0 + schunk * 8);
+                *reinterpret_cast<bf16x8*>(stg + row * SROW + schunk * 8) = rv;
+            }
+        }
+        __syncthreads();
+        const int frame = NF > 1 ? f0 + wm : f0;
+        const int b = frame / a.fpb;
+        float rinv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float tot = ss[j] + red[(wn ^ 1) * 256 + wm * 64 + j * 32 + l31];
+            rinv[j] = a.norm_scale / fmaxf(sqrtf(tot), 1e-12f);
+        }
+        const bool bok = frame < a.frames;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int ch = n0 + i * 32 + 8 * rg + 4 * h;
+                f32x4 gv = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+                if (bok) {
+                    gv = *reinterpret_cast<const f32x4*>(a.gain + b * a.gain_bs + ch);
+                    if (a.shift) sv = *reinterpret_cast<const f32x4*>(a.shift + b * a.shift_bs + ch);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j][4 * rg + e] = silu_f(fmaf(acc[i][j][4 * rg + e] * rinv[j], gv[e], sv[e]));
+            }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
+                __bf16* sp = stg + (j * 32 + l31) * SROW + i * 32 + 8 * rg + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e];
+                if constexpr (NORM) {
+                    if (a.res) {
+                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(sp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                    }
+                }
                 bf16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][4 * rg + e]);
-                *reinterpret_cast<bf16x4*>(stg + (j * 32 + l31) * SROW + i * 32 + 8 * rg + 4 * h) = o;
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+                *reinterpret_cast<bf16x4*>(sp) = o;
             }
     // (a wave reads back only what it wrote itself: no barrier)
-    const int srow0 = lane >> 3, schunk = lane & 7;
-    const long long row0 = (long long)tile * 256 + wm * 64;
     __bf16* op = a.out + (long long)ksp * a.out_split_stride + n0 + schunk * 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -288,9 +381,11 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
         const bf16x8 ov = *reinterpret_cast<const bf16x8*>(stg + row * SROW + schunk * 8);
         if (row0 + row < a.rows) *reinterpret_cast<bf16x8*>(op + (row0 + row) * a.ldo) = ov;
     }
+    DC_STAMP(5);
 }
 
 int g_dc_enabled = -1;
+int g_dc_norm_all = 0;      // tests: the normalisation epilogue on every image width the kernel is built for
 
 bool dc_covers(const vdmi_tapgemm_args& A) {
     if (g_dc_enabled < 0) {
@@ -299,7 +394,19 @@ bool dc_covers(const vdmi_tapgemm_args& A) {
     }
     if (!g_dc_enabled) return false;
     const vdmi_tap_pass& m = A.main;
-    if (A.epilogue != VDMI_EPI_PLAIN || A.act || A.has_res || A.n % 128 || A.tile_bn != 64) return false;
+    const bool norm = A.epilogue == VDMI_EPI_NORM_SILU;
+    if (norm) {
+        // the tile must hold every output channel of its pixels; residual: none or an identity tensor
+        if (A.n != 128 || A.has_res == 1 || !A.gain || A.frames_per_batch <= 0 || A.k_split > 1) return false;
+        // measured per launch of 8 samples: 32-pixel-wide images 42-45 -> 40-44 us, smaller images (80-tile launches)
+        // 17-18 -> 18-19 us against the tap-GEMM's fused epilogue: only the former take this kernel.  (The choice
+        // depends on the layer's shape alone, never on the batch.)
+        if (A.main.in_w != 32 && !g_dc_norm_all) return false;
+        if (A.has_res == 2 && (!A.res_identity || A.ld_res % 8 || !aligned16(A.res_identity))) return false;
+        if (A.gain_bstride % 4 || A.shift_bstride % 4 || !aligned16(A.gain) || (A.shift && !aligned16(A.shift))) return false;
+    } else if (A.epilogue != VDMI_EPI_PLAIN || A.act || A.has_res || A.n % 128 || A.tile_bn != 64) {
+        return false;
+    }
     if (m.ntaps != 9 || m.stride != 1 || m.c0 <= 0 || m.c0 % 64 || m.c1 % 64) return false;
     for (int t = 0; t < 9; ++t)
         if (m.dy[t] != t / 3 - 1 || m.dx[t] != t % 3 - 1) return false;
@@ -322,7 +429,7 @@ bool dc_covers(const vdmi_tapgemm_args& A) {
 
 }   // namespace
 
-extern "C" void vdmi_dconv_enable(int on) { g_dc_enabled = on ? 1 : 0; }
+extern "C" void vdmi_dconv_enable(int on) { g_dc_enabled = on ? 1 : 0; g_dc_norm_all = on > 1; }
 extern "C" int vdmi_dconv_covers(const vdmi_tapgemm_args* a) { return a && dc_covers(*a) ? 1 : 0; }
 
 // Runs `A` on the streaming kernel when the launch has its shape.  Returns VDMI_OK when it was launched, 1 when the
@@ -356,25 +463,38 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     k.src0_bytes = (unsigned)(k.rows * m.c0 * 2);
     k.src1_bytes = m.c1 ? (unsigned)(k.rows * m.c1 * 2) : 0u;
     k.w_bytes = (unsigned)((long long)k.nch * 9 * A.n * 64 * 2);
+    const bool norm = A.epilogue == VDMI_EPI_NORM_SILU;
+    k.gain = A.gain;
+    k.shift = A.shift;
+    k.gain_bs = A.gain_bstride;
+    k.shift_bs = A.shift_bstride;
+    k.res = (norm && A.has_res == 2) ? static_cast<const __bf16*>(A.res_identity) : nullptr;
+    k.ld_res = A.ld_res;
+    k.fpb = A.frames_per_batch > 0 ? A.frames_per_batch : 1;
+    k.norm_scale = A.norm_scale;
+    k.diag = nullptr;
+#ifdef VDMI_DIAG_STAMPS
+    if (const char* dp = std::getenv("VDMI_DIAG_PTR")) k.diag = reinterpret_cast<unsigned long long*>(std::strtoull(dp, nullptr, 0));
+#endif
     const long long nwg = (long long)k.npx * k.nnt * k.ksplit;
     if (nwg > 0x7fffffffLL) return VDMI_E_SHAPE;
 
-    static std::atomic<uint64_t> attr_mask[3];
+    static std::atomic<uint64_t> attr_mask[6];
     const int PW = W + 2, PR = R + 2, NF = 256 / (R * W);
     const int npiece = (NF * PR * PW + 7) / 8;
     const size_t lds = (size_t)2 * npiece * 1024 + 3 * 16384;
-    const size_t stg = (size_t)8 * 64 * 72 * 2;
+    const size_t stg = (size_t)8 * 64 * 72 * 2 + 2 * 256 * 4;
     const size_t need = lds > stg ? lds : stg;
-    if (W == 8) {
-        if (vdmi_set_max_lds(reinterpret_cast<const void*>(dconv_kernel<8, 8>), attr_mask[0], 160 * 1024)) return VDMI_E_LAUNCH;
-        hipLaunchKernelGGL((dconv_kernel<8, 8>), dim3((unsigned)nwg), dim3(512), need, stream, k);
-    } else if (W == 16) {
-        if (vdmi_set_max_lds(reinterpret_cast<const void*>(dconv_kernel<16, 16>), attr_mask[1], 160 * 1024)) return VDMI_E_LAUNCH;
-        hipLaunchKernelGGL((dconv_kernel<16, 16>), dim3((unsigned)nwg), dim3(512), need, stream, k);
-    } else {
-        if (vdmi_set_max_lds(reinterpret_cast<const void*>(dconv_kernel<32, 8>), attr_mask[2], 160 * 1024)) return VDMI_E_LAUNCH;
-        hipLaunchKernelGGL((dconv_kernel<32, 8>), dim3((unsigned)nwg), dim3(512), need, stream, k);
+#define VDMI_DC_CASE(W_, R_, NORM_, IDX_)                                                                          \
+    {                                                                                                              \
+        auto fn = dconv_kernel<W_, R_, NORM_>;                                                                     \
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(fn), attr_mask[IDX_], 160 * 1024)) return VDMI_E_LAUNCH; \
+        hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(512), need, stream, k);                                   \
     }
+    if (W == 8) { if (norm) VDMI_DC_CASE(8, 8, true, 0) else VDMI_DC_CASE(8, 8, false, 1) }
+    else if (W == 16) { if (norm) VDMI_DC_CASE(16, 16, true, 2) else VDMI_DC_CASE(16, 16, false, 3) }
+    else { if (norm) VDMI_DC_CASE(32, 8, true, 4) else VDMI_DC_CASE(32, 8, false, 5) }
+#undef VDMI_DC_CASE
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }

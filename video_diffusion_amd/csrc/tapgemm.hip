@@ -915,10 +915,13 @@ extern "C" int vdmi_tapgemm(const vdmi_tapgemm_args* args, vdmi_stream stream_) 
     if (A.k_split > 1 && (epi != VDMI_EPI_PLAIN || A.act || A.has_res || A.out_split_stride <= 0 || A.out_split_stride % 8))
         return VDMI_E_ARG;
 
-    // 64 -> 64 channel (1,3,3) convolutions of wide images: the weight-stationary kernel
+    // 64 -> 64 channel (1,3,3) convolutions of wide images: the weight-stationary kernel; 128 output channels on
+    // 8- to 32-pixel-wide images: the streaming kernel with the normalisation epilogue
     if (epi == VDMI_EPI_NORM_SILU) {
         const int ws = vdmi_wsconv_try(A, stream);
         if (ws <= 0) return ws;
+        const int dc = vdmi_dconv_try(A, stream);
+        if (dc <= 0) return dc;
     }
 
     // (1,3,3) convolutions of the wide, small-image layers: the streaming kernel
