@@ -32,6 +32,8 @@ def klass(name):
         return f"tapgemm<epi={m.group(6)},bn={m.group(2)}>"
     if "wsconv64_kernel" in name:
         return "wsconv64"
+    if "dconv_kernel" in name:
+        return "dconv"
     m = re.search(r"tattn_wide_kernel<\d+, \w+, (\d)>", name)
     if m:
         return ("tattn_fused", "sattn_fused", "sla_fused_wide")[int(m.group(1))]
