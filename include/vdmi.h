@@ -223,11 +223,32 @@ int vdmi_groupnorm(const void* x, void* out, int nsamples, int64_t rows_per_samp
                    const float* post_shift, int64_t post_bstride, const void* residual, int ld_res, void* workspace,
                    vdmi_stream stream);
 
+/* Backward of vdmi_groupnorm (the reference differentiates these layers through PyTorch autograd:
+ * video_diffusion_guidance.py:334-344, 378-382 under the guidance sampler's torch.autograd.grad at :725-761).
+ * x: the forward's input rows, dout: gradient rows [..][ld_dout] of the forward's output (the residual's gradient is dout
+ * itself), dx: gradient rows [..][c] of x.  chan_sums: float [nsamples][c][4] = per sample and channel
+ * {sum dy, sum dy * xhat, sum dout * act(y), sum dout}: summed over the samples the first two are dbeta and dgamma, the
+ * last two are the gradients of post_gain / post_shift.  No atomics: results are the same every call.
+ * `workspace`: vdmi_groupnorm_bwd_workspace_bytes() bytes. */
+size_t vdmi_groupnorm_bwd_workspace_bytes(int nsamples, int64_t rows_per_sample, int c, int groups);      /* HOST */
+int vdmi_groupnorm_bwd(const void* x, const void* dout, int ld_dout, void* dx, int nsamples, int64_t rows_per_sample,
+                       int c, int groups, const float* gamma, const float* beta, float eps, int act,
+                       const float* post_gain, int64_t post_bstride, float* chan_sums, void* workspace,
+                       vdmi_stream stream);
+
 /* Depthwise temporal convolution Conv3d(c, c, (k,1,1), padding (k/2,0,0), groups=c) of
  * video_diffusion_guidance.py:324-325 over channels-last bf16 rows [b*f*hw][ldx] -> [b*f*hw][ldo] (the first c
  * columns of each); w: float [c][k], bias: float [c] or NULL; k odd. */
 int vdmi_temporal_dwconv(const void* x, int ldx, void* out, int ldo, int b, int f, int64_t hw, int c, int k,
                          const float* w, const float* bias, vdmi_stream stream);
+
+/* Weight and bias gradient of vdmi_temporal_dwconv from its input rows x and output-gradient rows du (both [b*f*hw][c]):
+ * part: float [*nsplit_out][c][k + 1] partial sums (vdmi_temporal_dwconv_wgrad_elems() floats); summed over the first
+ * axis, [..][j] (j < k) is the gradient of w[ch][j] and [..][k] that of the bias.  k: 1, 3, 5 or 7.  (The gradient with
+ * respect to x is vdmi_temporal_dwconv itself with the taps reversed.) */
+size_t vdmi_temporal_dwconv_wgrad_elems(int b, int f, int64_t hw, int c, int k);                          /* HOST */
+int vdmi_temporal_dwconv_wgrad(const void* x, const void* du, float* part, int* nsplit_out, int b, int f, int64_t hw,
+                               int c, int k, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Softmax attention core over a small token axis (temporal attention over frames with

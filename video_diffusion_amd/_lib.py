@@ -126,6 +126,13 @@ _SIGNATURES = {
                                  C.c_void_p]),
     "vdmi_temporal_dwconv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdmi_groupnorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "vdmi_groupnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "vdmi_temporal_dwconv_wgrad_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "vdmi_temporal_dwconv_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                             C.c_int, C.c_int, C.c_void_p]),
     "vdmi_xattn_kv_elems": (C.c_size_t, [C.c_int] * 4),
     "vdmi_xattn_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vdmi_xattn_pack_kv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

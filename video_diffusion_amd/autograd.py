@@ -323,23 +323,47 @@ def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null
 
 
 def guidance_variant_forward(unet, x, time):
-    """Unet3D.forward of the reference's video_diffusion_guidance.py (:596-635) as differentiable torch ops over the
-    parameters of a guidance_variant.Unet3D: the reference's guidance sampler differentiates the reconstruction loss
+    """Unet3D.forward of the reference's video_diffusion_guidance.py (:596-635) as a differentiable function of x and of
+    the parameters of a guidance_variant.Unet3D: the reference's guidance sampler differentiates the reconstruction loss
     through this denoiser (video_diffusion_guidance.py:725-761, 860-900).  Used only when a gradient is asked for;
-    sampling runs on the HIP plan."""
-    bias = _pos_bias(unet, x.shape[2], x.device)
+    sampling runs on the HIP plan.  `unet.train_backend == "hip"`: the layers run forward and backward on the HIP kernels
+    (train_hip_variant.py) over a bf16 activation stream; otherwise torch ops in float."""
+    global _HIP_RESNET, _HIP_ATTN
+    hip = getattr(unet, "train_backend", None) == "hip" and x.is_cuda
+    prev = (_HIP_RESNET, _HIP_ATTN)
+    _HIP_RESNET, _HIP_ATTN = hip, hip
+    try:
+        return _guidance_variant_forward(unet, x, time, hip)
+    finally:
+        _HIP_RESNET, _HIP_ATTN = prev
 
-    def tattn(res, x):
+
+def _guidance_variant_forward(unet, x, time, hip):
+    bias = _pos_bias(unet, x.shape[2], x.device)
+    if hip:
+        from . import train_hip_variant as HV
+        from .train_hip import init_conv, pointwise_conv
+
+    def tattn_ops(res, x):
         # Residual(PreNorm(TemporalAttention)), :390-428: attention over the frames of every position
         b, c, f, h, w = x.shape
         y = _chan_layernorm(x, res.fn.norm).permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
         return _attention(res.fn.fn, y, bias).reshape(b, h, w, f, c).permute(0, 4, 3, 1, 2) + x
 
-    def sattn(res, x):
+    def sattn_ops(res, x):
         # Residual(PreNorm(SpatialAttention)), :431-459: attention over the positions of every frame
         b, c, f, h, w = x.shape
         y = _chan_layernorm(x, res.fn.norm).permute(0, 2, 3, 4, 1).reshape(b, f, h * w, c)
         return _attention(res.fn.fn, y).reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3) + x
+
+    def tattn(res, x):
+        if hip:
+            rot = _rot_tables(getattr(res.fn.fn, "rotary_emb", None), x.shape[2], x.device)
+            return HV.temporal_attention(res, x, bias, rot, lambda y: tattn_ops(res, y))
+        return tattn_ops(res, x)
+
+    def sattn(res, x):
+        return HV.spatial_attention(res, x, lambda y: sattn_ops(res, y)) if hip else sattn_ops(res, x)
 
     def ts(tb, x):
         # TemporalSpatialBlock, :334-344
@@ -348,6 +372,8 @@ def guidance_variant_forward(unet, x, time):
 
     def rb(blk, x, temb=None):
         # ResnetBlock, :370-388: the time embedding acts between the two blocks
+        if hip:
+            return HV.resnet_block(blk, x, temb)
         res = blk.res_conv(x)
         h = ts(blk.ts_block1, x)
         if blk.mlp is not None and temb is not None:
@@ -355,7 +381,8 @@ def guidance_variant_forward(unet, x, time):
             h = h * (scale + 1) + shift
         return ts(blk.ts_block2, h) + res
 
-    x = tattn(unet.init_temporal_attn, unet.init_conv(x))
+    x = init_conv(unet.init_conv, x, torch.bfloat16) if hip else unet.init_conv(x)
+    x = tattn(unet.init_temporal_attn, x)
     r = x
     half = unet.dim // 2
     freq = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
@@ -365,11 +392,12 @@ def guidance_variant_forward(unet, x, time):
     for b1, b2, ta, sa, down in unet.downs:
         x = sattn(sa, tattn(ta, rb(b2, rb(b1, x, t), t)))
         skips.append(x)
-        x = down(x)
+        x = _resample(down, x)
     x = rb(unet.mid_block1, x, t)
     x = rb(unet.mid_block2, sattn(unet.mid_spatial_attn, tattn(unet.mid_temporal_attn, x)), t)
     for b1, b2, ta, sa, up in unet.ups:
         x = torch.cat((x, skips.pop()), dim=1)
-        x = up(sattn(sa, tattn(ta, rb(b2, rb(b1, x, t), t))))
+        x = _resample(up, sattn(sa, tattn(ta, rb(b2, rb(b1, x, t), t))))
     x = torch.cat((x, r), dim=1)
-    return unet.final_conv[1](rb(unet.final_conv[0], x))         # :591-594, 635: the final block gets no embedding
+    x = rb(unet.final_conv[0], x)                                 # :591-594, 635: the final block gets no embedding
+    return pointwise_conv(unet.final_conv[1], x) if hip else unet.final_conv[1](x)

@@ -1002,6 +1002,281 @@ extern "C" int vdmi_temporal_dwconv(const void* x, int ldx, void* out, int ldo, 
     return VDMI_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward of vdmi_groupnorm (the GroupNorm -> SiLU -> time scale / shift chain of video_diffusion_guidance.py:334-344,
+// 378-382, differentiated by the guidance sampler at :725-761).  With xh = (x - mean) * rstd, y = gamma * xh + beta,
+// z = act(y), out = z * post_gain + post_shift (+ residual):
+//     dy  = dout * post_gain * act'(y)                      dxh = dy * gamma
+//     dx  = rstd * (dxh - mean_g(dxh) - xh * mean_g(dxh * xh))          (means over the sample's group)
+// The group means follow from per-channel sums: sum_g(dxh) = sum_c gamma_c * A_c, sum_g(dxh * xh) = sum_c gamma_c * B_c
+// with A_c = sum dy (the sample's share of dbeta) and B_c = sum dy * xh (of dgamma).  Four launches, no atomics (every
+// sum has a fixed order): statistics of x (the forward's first pass), per-(sample, split, channel) partial sums
+// {A, B, P = sum dout * z, Q = sum dout}, their reduction per sample (+ the group terms), the element pass.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dsilu_f(float y) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
+    return s * fmaf(y, 1.0f - s, 1.0f);
+}
+
+__device__ __forceinline__ void groupnorm_stats_of_sample(const float* __restrict__ part, int nsplit, int ppr, int ppg,
+                                                          int groups, int b, float cnt, float eps, float* mean_s,
+                                                          float* rstd_s) {
+    const int tid = threadIdx.x;
+    if (tid < groups) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp)
+            for (int q = 0; q < ppg; ++q) {
+                const float* src = part + (((long long)b * nsplit + sp) * ppr + tid * ppg + q) * 2;
+                a1 += src[0];
+                a2 += src[1];
+            }
+        const float mean = a1 / cnt;
+        mean_s[tid] = mean;
+        rstd_s[tid] = rsqrtf(fmaxf(a2 / cnt - mean * mean, 0.f) + eps);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void groupnorm_bwd_partial_kernel(
+    const __bf16* __restrict__ x, const __bf16* __restrict__ dout, int ld_dout, long long rows_per_sample, int c, int groups,
+    const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
+    const float* __restrict__ post_gain, long long post_bstride, float* __restrict__ part2) {
+    __shared__ float mean_s[256], rstd_s[256];
+    __shared__ float sm[8][256];
+    const int ppr = c / 8, rpi = 256 / ppr, ppg = ppr / groups;
+    const int tid = threadIdx.x, piece = tid % ppr, r0 = tid / ppr;
+    const int nsplit = gridDim.x, split = blockIdx.x, b = blockIdx.y;
+    groupnorm_stats_of_sample(part, nsplit, ppr, ppg, groups, b, (float)rows_per_sample * (float)(c / groups), eps, mean_s,
+                              rstd_s);
+    const float mean = mean_s[piece / ppg], rstd = rstd_s[piece / ppg];
+    float ga[8], be[8], pg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ga[e] = gamma[piece * 8 + e];
+        be[e] = beta[piece * 8 + e];
+        pg[e] = post_gain ? post_gain[b * post_bstride + piece * 8 + e] : 1.f;
+    }
+    const long long per = (rows_per_sample + nsplit - 1) / nsplit;
+    const long long lo = split * per, hi = lo + per < rows_per_sample ? lo + per : rows_per_sample;
+    const long long row0 = (long long)b * rows_per_sample;
+    float acc[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+    for (long long r = lo + r0; r < hi; r += rpi) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (row0 + r) * c + piece * 8);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dout + (row0 + r) * ld_dout + piece * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)v[e] - mean) * rstd;
+            const float y = fmaf(ga[e], xh, be[e]);
+            const float dd = (float)d[e];
+            const float dy = dd * pg[e] * (act ? dsilu_f(y) : 1.f);
+            acc[0][e] += dy;
+            acc[1][e] = fmaf(dy, xh, acc[1][e]);
+            acc[2][e] = fmaf(dd, act ? silu_f(y) : y, acc[2][e]);
+            acc[3][e] += dd;
+        }
+    }
+    float* dst = part2 + ((long long)b * nsplit + split) * c * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm[e][tid] = acc[q][e];
+        __syncthreads();
+        for (int ch = tid; ch < c; ch += 256) {
+            float s = 0.f;
+            for (int j = ch >> 3; j < 256; j += ppr) s += sm[ch & 7][j];
+            dst[ch * 4 + q] = s;
+        }
+    }
+}
+
+// per sample: chan[b][c][4] = the partial sums over the splits; gsum[b][groups][4] = {mean, rstd, mean_g(dxh), mean_g(dxh*xh)}
+__global__ __launch_bounds__(256) void groupnorm_bwd_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part2,
+                                                                   int nsplit, long long rows_per_sample, int c, int groups,
+                                                                   const float* __restrict__ gamma, float eps,
+                                                                   float* __restrict__ chan, float* __restrict__ gsum) {
+    __shared__ float mean_s[256], rstd_s[256];
+    __shared__ float ga_s[2048], gb_s[2048];
+    const int tid = threadIdx.x, b = blockIdx.x, ppr = c / 8, ppg = ppr / groups, cpg = c / groups;
+    const float cnt = (float)rows_per_sample * (float)cpg;
+    groupnorm_stats_of_sample(part, nsplit, ppr, ppg, groups, b, cnt, eps, mean_s, rstd_s);
+    for (int ch = tid; ch < c; ch += 256) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(part2 + (((long long)b * nsplit + sp) * c + ch) * 4);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+        *reinterpret_cast<float4*>(chan + ((long long)b * c + ch) * 4) = make_float4(s[0], s[1], s[2], s[3]);
+        ga_s[ch] = gamma[ch] * s[0];
+        gb_s[ch] = gamma[ch] * s[1];
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < cpg; ++j) { s1 += ga_s[tid * cpg + j]; s2 += gb_s[tid * cpg + j]; }
+        *reinterpret_cast<float4*>(gsum + ((long long)b * groups + tid) * 4) =
+            make_float4(mean_s[tid], rstd_s[tid], s1 / cnt, s2 / cnt);
+    }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_bwd_apply_kernel(
+    const __bf16* __restrict__ x, const __bf16* __restrict__ dout, int ld_dout, __bf16* __restrict__ dx,
+    long long rows_per_sample, int c, int groups, const float* __restrict__ gsum, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int act, const float* __restrict__ post_gain, long long post_bstride) {
+    const int ppr = c / 8, rpi = 256 / ppr, ppg = ppr / groups;
+    const int tid = threadIdx.x, piece = tid % ppr, r0 = tid / ppr;
+    const int b = blockIdx.y;
+    const float4 gs = *reinterpret_cast<const float4*>(gsum + ((long long)b * groups + piece / ppg) * 4);
+    const float mean = gs.x, rstd = gs.y, m1 = gs.z, m2 = gs.w;
+    float ga[8], be[8], pg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ga[e] = gamma[piece * 8 + e];
+        be[e] = beta[piece * 8 + e];
+        pg[e] = post_gain ? post_gain[b * post_bstride + piece * 8 + e] : 1.f;
+    }
+    const long long per = (rows_per_sample + gridDim.x - 1) / gridDim.x;
+    const long long lo = blockIdx.x * per, hi = lo + per < rows_per_sample ? lo + per : rows_per_sample;
+    const long long row0 = (long long)b * rows_per_sample;
+    for (long long r = lo + r0; r < hi; r += rpi) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (row0 + r) * c + piece * 8);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dout + (row0 + r) * ld_dout + piece * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)v[e] - mean) * rstd;
+            const float y = fmaf(ga[e], xh, be[e]);
+            const float dxh = (float)d[e] * pg[e] * (act ? dsilu_f(y) : 1.f) * ga[e];
+            o[e] = f2bf(rstd * (dxh - m1 - xh * m2));
+        }
+        *reinterpret_cast<bf16x8*>(dx + (row0 + r) * c + piece * 8) = o;
+    }
+}
+
+// Weight and bias gradient of the depthwise temporal convolution: part[split][c][K + 1] = per-split sums of
+// du[r][ch] * x[r + (j - K/2) * hw][ch] over the split's rows (frames outside the clip contribute nothing), j < K, and
+// of du[r][ch] (the bias) at j = K.
+template <int K>
+__global__ __launch_bounds__(256) void temporal_dwconv_wgrad_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ du,
+                                                                    long long rows, int f, long long hw, int c,
+                                                                    float* __restrict__ part) {
+    __shared__ float sm[8][256];
+    const int ppr = c / 8, rpi = 256 / ppr;
+    const int tid = threadIdx.x, piece = tid % ppr, r0 = tid / ppr;
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long lo = blockIdx.x * per, hi = lo + per < rows ? lo + per : rows;
+    float acc[K + 1][8];
+#pragma unroll
+    for (int j = 0; j <= K; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+    for (long long r = lo + r0; r < hi; r += rpi) {
+        const int fr = (int)((r / hw) % f);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(du + r * c + piece * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[K][e] += (float)d[e];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int ff = fr + j - K / 2;
+            if (ff < 0 || ff >= f) continue;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (r + (long long)(j - K / 2) * hw) * c + piece * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] = fmaf((float)d[e], (float)v[e], acc[j][e]);
+        }
+    }
+    float* dst = part + (long long)blockIdx.x * c * (K + 1);
+#pragma unroll
+    for (int j = 0; j <= K; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm[e][tid] = acc[j][e];
+        __syncthreads();
+        for (int ch = tid; ch < c; ch += 256) {
+            float s = 0.f;
+            for (int q = ch >> 3; q < 256; q += ppr) s += sm[ch & 7][q];
+            dst[ch * (K + 1) + j] = s;
+        }
+    }
+}
+
+static bool groupnorm_shape_ok(int nsamples, int64_t rows_per_sample, int c, int groups) {
+    return !(nsamples <= 0 || nsamples > 65535 || rows_per_sample <= 0 || c < 64 || c > 2048 || 256 % (c / 8) || c % 8 ||
+             groups <= 0 || groups > 256 || c % groups || (c / groups) % 8);
+}
+
+extern "C" size_t vdmi_groupnorm_bwd_workspace_bytes(int nsamples, int64_t rows_per_sample, int c, int groups) {
+    if (!groupnorm_shape_ok(nsamples, rows_per_sample, c, groups)) return 0;
+    const size_t nsplit = groupnorm_splits(rows_per_sample);
+    return ((size_t)nsamples * nsplit * (c / 8) * 2 + (size_t)nsamples * nsplit * c * 4 + (size_t)nsamples * groups * 4) *
+           sizeof(float);
+}
+
+extern "C" int vdmi_groupnorm_bwd(const void* x, const void* dout, int ld_dout, void* dx, int nsamples, int64_t rows_per_sample,
+                                  int c, int groups, const float* gamma, const float* beta, float eps, int act,
+                                  const float* post_gain, int64_t post_bstride, float* chan_sums, void* workspace,
+                                  vdmi_stream stream_) {
+    if (!x || !dout || !dx || !gamma || !beta || !chan_sums || !workspace) return VDMI_E_ARG;
+    if (act < 0 || act > 1) return VDMI_E_ARG;
+    if (!groupnorm_shape_ok(nsamples, rows_per_sample, c, groups) || ld_dout < c || ld_dout % 8) return VDMI_E_SHAPE;
+    if (!aligned16(x) || !aligned16(dout) || !aligned16(dx) || !aligned16(chan_sums) || !aligned16(workspace))
+        return VDMI_E_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int nsplit = groupnorm_splits(rows_per_sample);
+    float* part = static_cast<float*>(workspace);
+    float* part2 = part + (size_t)nsamples * nsplit * (c / 8) * 2;
+    float* gsum = part2 + (size_t)nsamples * nsplit * c * 4;
+    const dim3 grid((unsigned)nsplit, (unsigned)nsamples);
+    const __bf16* xb = static_cast<const __bf16*>(x);
+    const __bf16* db = static_cast<const __bf16*>(dout);
+    hipLaunchKernelGGL(groupnorm_partial_kernel, grid, dim3(256), 0, stream, xb, (long long)rows_per_sample, c, part);
+    VDMI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(groupnorm_bwd_partial_kernel, grid, dim3(256), 0, stream, xb, db, ld_dout, (long long)rows_per_sample, c,
+                       groups, part, gamma, beta, eps, act, post_gain, (long long)post_bstride, part2);
+    VDMI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(groupnorm_bwd_reduce_kernel, dim3((unsigned)nsamples), dim3(256), 0, stream, part, part2, nsplit,
+                       (long long)rows_per_sample, c, groups, gamma, eps, chan_sums, gsum);
+    VDMI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, grid, dim3(256), 0, stream, xb, db, ld_dout, static_cast<__bf16*>(dx),
+                       (long long)rows_per_sample, c, groups, gsum, gamma, beta, act, post_gain, (long long)post_bstride);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+static int dwconv_wgrad_splits(long long rows) {
+    long long n = rows / 256;
+    return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
+}
+
+extern "C" size_t vdmi_temporal_dwconv_wgrad_elems(int b, int f, int64_t hw, int c, int k) {
+    if (b <= 0 || f <= 0 || hw <= 0 || c <= 0 || k < 1) return 0;
+    return (size_t)dwconv_wgrad_splits((long long)b * f * hw) * c * (k + 1);
+}
+
+extern "C" int vdmi_temporal_dwconv_wgrad(const void* x, const void* du, float* part, int* nsplit_out, int b, int f,
+                                          int64_t hw, int c, int k, vdmi_stream stream_) {
+    if (!x || !du || !part || !nsplit_out) return VDMI_E_ARG;
+    if (b <= 0 || f <= 0 || hw <= 0 || c < 8 || c > 2048 || c % 8 || 256 % (c / 8)) return VDMI_E_SHAPE;
+    if (k != 1 && k != 3 && k != 5 && k != 7) return VDMI_E_SHAPE;
+    if (!aligned16(x) || !aligned16(du)) return VDMI_E_ALIGN;
+    const long long rows = (long long)b * f * hw;
+    const int nsplit = dwconv_wgrad_splits(rows);
+    *nsplit_out = nsplit;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const __bf16* xb = static_cast<const __bf16*>(x);
+    const __bf16* db = static_cast<const __bf16*>(du);
+#define VDMI_DWW(K)                                                                                                        \
+    hipLaunchKernelGGL(temporal_dwconv_wgrad_kernel<K>, dim3((unsigned)nsplit), dim3(256), 0, stream, xb, db, rows, f,     \
+                       (long long)hw, c, part)
+    if (k == 1) VDMI_DWW(1); else if (k == 3) VDMI_DWW(3); else if (k == 5) VDMI_DWW(5); else VDMI_DWW(7);
+#undef VDMI_DWW
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
 extern "C" int vdmi_rmsnorm_silu_sum(const void* x, int nparts, int64_t part_stride, int ldx, void* out, int ldo, int64_t rows,
                                      int c, const float* gain, int64_t gain_bstride, const float* shift,
                                      int64_t shift_bstride, int64_t rows_per_batch, float norm_scale, const void* res,

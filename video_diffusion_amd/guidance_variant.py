@@ -137,14 +137,21 @@ class Unet3D(nn.Module):
             object.__setattr__(self, "_engine", GuidanceEngine(self))
         return self._engine
 
+    def hip_training_supported(self) -> bool:
+        from . import train_hip_variant
+        return train_hip_variant.supports(self)
+
     def forward(self, x, time):
         if torch.is_grad_enabled() and (x.requires_grad or self.train_backend is not None):
             # a gradient with respect to x_t (the guidance sampler, video_diffusion_guidance.py:725-761) or to the
-            # parameters (training): torch ops over the same parameters, as the reference differentiates; the HIP plan of
-            # this variant is forward-only
-            if self.train_backend not in (None, "torch-autograd"):
-                raise _lib.VdmiError(f"guidance_variant.Unet3D trains through torch ops only (train_backend "
-                                     f"'torch-autograd'), not {self.train_backend!r}")
+            # parameters (training): "hip" = every layer forward and backward on the HIP kernels (train_hip_variant.py),
+            # None / "torch-autograd" = torch ops over the same parameters, as the reference differentiates
+            if self.train_backend not in (None, "torch-autograd", "hip"):
+                raise _lib.VdmiError(f"guidance_variant.Unet3D differentiates through train_backend 'hip' or "
+                                     f"'torch-autograd', not {self.train_backend!r}")
+            if self.train_backend == "hip" and not (x.is_cuda and self.hip_training_supported()):
+                raise _lib.VdmiError("train_backend 'hip' needs CUDA (HIP) tensors and layer shapes the training kernels "
+                                     "take (train_hip_variant.supports); there is no CPU path")
             from .autograd import guidance_variant_forward
             return guidance_variant_forward(self, x, time)
         return self.engine().forward(x, time)

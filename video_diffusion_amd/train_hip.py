@@ -66,9 +66,9 @@ def torch_ops(fn, *xs):
     (outside autocast the layer's float parameters would not take them), the result goes back to the stream's dtype."""
     if xs[0].dtype != torch.bfloat16:
         return fn(*xs)
-    if not torch.is_autocast_enabled():
-        xs = tuple(x.float() for x in xs)
-    return fn(*xs).to(torch.bfloat16)
+    # widened whatever the autocast state: under autocast the layer's matmuls still run in bf16, but its normalisations and
+    # softmax then see float inputs, as they do in the all-torch path
+    return fn(*(x.float() for x in xs)).to(torch.bfloat16)
 
 
 class DevPack:

@@ -307,7 +307,9 @@ class Trainer(object):
             backend = self.train_backend
             if backend == "auto":      # the HIP layers when the model's shapes allow them, else torch ops throughout
                 from . import train_hip
-                backend = "hip" if (dev.type == "cuda" and train_hip.supports(self.model.denoise_fn)) else "torch-autograd"
+                own = getattr(self.model.denoise_fn, "hip_training_supported", None)   # the guidance variant's own layers
+                fits = own() if own is not None else train_hip.supports(self.model.denoise_fn)
+                backend = "hip" if (dev.type == "cuda" and fits) else "torch-autograd"
             self.model.denoise_fn.train_backend = backend
         loss_core = _LossModule(self.model, self.null_frame_cond_prob)
         loss_mod = loss_core

@@ -180,7 +180,9 @@ def temporal_consistency_guidance(model, prev_frames, overlap_frames, w_r=1.0):
                     p.requires_grad_(False)
                 if hasattr(fn, "train_backend"):
                     from . import train_hip
-                    fn.train_backend = "hip" if (z.is_cuda and train_hip.supports(fn)) else "torch-autograd"
+                    own = getattr(fn, "hip_training_supported", None)     # the guidance variant answers for its own layers
+                    fits = own() if own is not None else train_hip.supports(fn)
+                    fn.train_backend = "hip" if (z.is_cuda and fits) else "torch-autograd"
                 from . import train_hip as _th
                 with _th.fixed_weights(packs):
                     x_recon = model.predict_start_from_noise(z, t, fn(z, t))
