@@ -408,10 +408,13 @@ int vdmi_ddpm_step_rng(const float* x, const float* eps, const int64_t* t, const
 /* vdmi_ddpm_step_rng for a loop replayed from a captured HIP graph (p_sample_loop, vdp.py:1004-1014: t runs from
  * T - 1 down to 0): after the step, the workgroup that finishes last replaces every t[i] by t[i] - 1, or by
  * timesteps - 1 when t[i] was 0, so the host never writes t between replays.  done_counter: one uint32 in device
- * memory, zero before the first call (the kernel leaves it at zero). */
+ * memory, zero before the first call (the kernel leaves it at zero).  The b samples may be samples
+ * [batch_offset, batch_offset + b) of a batch of batch_total (0: b) that other calls step independently - samples never
+ * interact in the loop - and they then draw the noise one call over the whole batch would draw: sample i counts as
+ * (t * batch_total + batch_offset + i). */
 int vdmi_ddpm_step_loop(const float* x, const float* eps, int64_t* t, const vdmi_ddpm_coefs* coefs, float* out, int b,
                         int64_t per_sample, int clip, const uint64_t* rng_state, uint32_t* done_counter, int timesteps,
-                        vdmi_stream stream);
+                        int batch_total, int batch_offset, vdmi_stream stream);
 
 /* Dynamic thresholding of the predicted x0 (vdp.py:957-968, 987-997; use_dynamic_thres of GaussianDiffusion):
  *   thres[i] = max(1, torch.quantile(|x0_i|, percentile))   over the per_sample elements of sample i,

@@ -133,6 +133,13 @@ def test_graph_replay_equals_eager_loop_with_philox():
     gd.use_hip_graph = False
     b = gd.p_sample_loop(shape, x_T=x_T)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+    # the parts of the batch as independent loops (one graph and stream per part, no join between steps, the second
+    # started later): the same noise field, the same bits
+    torch.manual_seed(77)
+    gd.use_hip_graph, gd.pipeline_parts, gd.pipeline_stagger_s = True, True, 2e-3
+    c = gd.p_sample_loop(shape, x_T=x_T)
+    assert any(k[-1] is True for k in gd._graphs if k[0] != "cond")
+    assert torch.equal(a, c)
 
 
 def test_dynamic_threshold_loop_graph_equals_eager_and_torch_expressions():

@@ -147,7 +147,7 @@ _SIGNATURES = {
     "vdmi_ddpm_step_rng": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p, C.c_int,
                                      C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "vdmi_ddpm_step_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p, C.c_int,
-                                      C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                                      C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vdmi_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs),
                                  C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vdmi_dynamic_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p, C.c_int,

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
                                                         long long groups_per_sample, int clip, uint64_t seed,
                                                         uint64_t offset, const uint64_t* __restrict__ rng,
                                                         const float* __restrict__ thres, long long* t_next,
-                                                        unsigned* done, int t_wrap) {
+                                                        unsigned* done, int t_wrap, int b_total, int b_off) {
     // rng != null: key and counter offset live in device memory (a captured graph then draws what the buffer says)
     if (rng) { seed = rng[0]; offset = rng[1]; }
     const int b = blockIdx.y;
@@ -512,7 +512,8 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
         }
         // the counter includes t, which lives on the device, so a captured graph draws fresh noise each replay
         if (!z)
-            normal4(((uint64_t)tb * gridDim.y + (uint64_t)b) * (uint64_t)groups_per_sample + (uint64_t)g + offset, seed, zv);
+            normal4(((uint64_t)tb * (uint64_t)b_total + (uint64_t)(b_off + b)) * (uint64_t)groups_per_sample + (uint64_t)g + offset,
+                    seed, zv);
         float ov[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -651,12 +652,16 @@ static int ddpm_step_launch(const float* x, const float* eps, const float* z, co
                             const vdmi_ddpm_coefs* coefs, float* out, int b, int64_t per_sample, int clip,
                             uint64_t seed, uint64_t offset, const uint64_t* rng, vdmi_stream stream,
                             const float* thres = nullptr, long long* t_next = nullptr, unsigned* done = nullptr,
-                            int t_wrap = 0) {
+                            int t_wrap = 0, int b_total = 0, int b_off = 0) {
     if (!x || !eps || !t || !coefs || !out) return VDMI_E_ARG;
     if (!coefs->sqrt_recip_alphas_cumprod || !coefs->sqrt_recipm1_alphas_cumprod || !coefs->posterior_mean_coef1 ||
         !coefs->posterior_mean_coef2 || !coefs->posterior_log_variance_clipped)
         return VDMI_E_ARG;
     if (b <= 0 || b > 65535 || per_sample <= 0) return VDMI_E_SHAPE;
+    // the noise counter runs over the samples of the whole batch: a launch over samples [b_off, b_off + b) of b_total draws
+    // what one launch over all of them would
+    if (b_total == 0) b_total = b;
+    if (b_off < 0 || b_off + b > b_total) return VDMI_E_SHAPE;
     if ((per_sample & 3) == 0 && (!aligned16(x) || !aligned16(eps) || !aligned16(out) || (z && !aligned16(z))))
         return VDMI_E_ALIGN;
     const long long groups = (per_sample + 3) / 4;
@@ -664,7 +669,7 @@ static int ddpm_step_launch(const float* x, const float* eps, const float* z, co
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)bx, (unsigned)b), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, eps, z, t, *coefs, out, (long long)per_sample, groups, clip,
-                       seed, offset, rng, thres, t_next, done, t_wrap);
+                       seed, offset, rng, thres, t_next, done, t_wrap, b_total, b_off);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
@@ -684,10 +689,10 @@ extern "C" int vdmi_ddpm_step_rng(const float* x, const float* eps, const int64_
 
 extern "C" int vdmi_ddpm_step_loop(const float* x, const float* eps, int64_t* t, const vdmi_ddpm_coefs* coefs, float* out,
                                    int b, int64_t per_sample, int clip, const uint64_t* rng_state, uint32_t* done_counter,
-                                   int timesteps, vdmi_stream stream) {
+                                   int timesteps, int batch_total, int batch_offset, vdmi_stream stream) {
     if (!rng_state || (reinterpret_cast<uintptr_t>(rng_state) & 7u) || !done_counter || timesteps <= 0) return VDMI_E_ARG;
     return ddpm_step_launch(x, eps, nullptr, t, coefs, out, b, per_sample, clip, 0, 0, rng_state, stream, nullptr,
-                            reinterpret_cast<long long*>(t), done_counter, timesteps);
+                            reinterpret_cast<long long*>(t), done_counter, timesteps, batch_total, batch_offset);
 }
 
 extern "C" int vdmi_dynamic_threshold(const float* x, const float* eps, const int64_t* t, const vdmi_ddpm_coefs* coefs,

@@ -6,6 +6,8 @@ loop replays one captured HIP graph per step when the denoiser is the HIP Unet3D
 from __future__ import annotations
 
 import ctypes as C
+import os
+import time
 
 import torch
 import torch.nn.functional as F
@@ -39,6 +41,39 @@ def cosine_beta_schedule(timesteps, s=0.008):
     alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
     betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
     return torch.clip(betas, 0, 0.9999)
+
+
+class _StaggeredSteps:
+    """replay(): one denoising step of every part, each from its own captured graph on its own stream.  begin() orders
+    the part streams behind the work already queued on the current stream (the copy of x_T), finish() orders the
+    current stream behind the parts.  The first replay after begin() launches the parts `stagger_s` apart (the host
+    sleeps in between; every later launch just queues behind the part's previous step)."""
+
+    def __init__(self, graphs, streams, counters, device, stagger_s):
+        self.graphs, self.streams, self.counters, self.device, self.stagger_s = graphs, streams, counters, device, stagger_s
+        self._begun = self._first = False
+
+    def begin(self):
+        main = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(main)
+        self._begun = self._first = True
+
+    def replay(self):
+        if not self._begun:
+            self.begin()
+        for k, (g, s) in enumerate(zip(self.graphs, self.streams)):
+            if k and self._first and self.stagger_s > 0:
+                time.sleep(self.stagger_s)
+            with torch.cuda.stream(s):
+                g.replay()
+        self._first = False
+
+    def finish(self):
+        main = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            main.wait_stream(s)
+        self._begun = False
 
 
 class GaussianDiffusion(nn.Module):
@@ -99,6 +134,14 @@ class GaussianDiffusion(nn.Module):
         # "philox": drawn inside the step kernel (no extra pass over HBM).
         self.noise_source = "torch"
         self.use_hip_graph = True
+        # True: a batch that the engine runs as sub-batch plans loops part by part, each part on its own stream with
+        # nothing joining them between steps (samples never interact, vdp.py:1004-1014), the second part started
+        # pipeline_stagger_s after the first.  False (default): one graph per step, the parts forked and joined inside it.
+        # Same bits either way; measured on configs[1] the two take the same time whatever the stagger (3.63-3.65 ms per
+        # step: the compute units are busy throughout, so moving one part's small-image layers beside the other's
+        # large-image layers gains nothing).
+        self.pipeline_parts = os.environ.get("VDMI_PIPELINE", "0") != "0"
+        self.pipeline_stagger_s = float(os.environ.get("VDMI_PIPELINE_STAGGER_US", "0")) * 1e-6
         self._graphs = {}
         self._rng = {}
 
@@ -159,11 +202,13 @@ class GaussianDiffusion(nn.Module):
         return seed
 
     def ddpm_step(self, x, eps, t, noise=None, clip_denoised=True, out=None, seed=0, offset=0, rng_state=None,
-                  advance_t=None):
+                  advance_t=None, batch_slice=(0, 0)):
         """x_{t-1} from (x_t, eps, noise) in one HIP kernel.  noise=None draws Philox noise in-kernel, keyed by
         (seed, offset) or, when rng_state (device int64 [2]) is given, by the two words it holds.
         advance_t (device int32 [1], zero; needs rng_state and the static clip): the kernel also moves t on to t - 1
-        (num_timesteps - 1 after 0), for captured steps that are replayed without the host writing t."""
+        (num_timesteps - 1 after 0), for captured steps that are replayed without the host writing t; batch_slice =
+        (total, first): x holds samples [first, first + b) of a batch of `total` that is stepped in independent parts, and
+        draws the noise the whole batch would."""
         if not x.is_cuda:
             raise _lib.VdmiError("ddpm_step runs on the HIP device only")
         x = x.contiguous()
@@ -189,7 +234,7 @@ class GaussianDiffusion(nn.Module):
             check(_lib.lib().vdmi_ddpm_step_loop(
                 x.data_ptr(), eps.data_ptr(), t.data_ptr(), C.byref(self._coefs()), out.data_ptr(), b, x.numel() // b,
                 int(bool(clip_denoised)), rng_state.data_ptr(), advance_t.data_ptr(), int(self.num_timesteps),
-                torch.cuda.current_stream().cuda_stream), "vdmi_ddpm_step_loop")
+                int(batch_slice[0]), int(batch_slice[1]), torch.cuda.current_stream().cuda_stream), "vdmi_ddpm_step_loop")
             return out
         if noise is None and rng_state is not None:
             check(_lib.lib().vdmi_ddpm_step_rng(
@@ -228,7 +273,7 @@ class GaussianDiffusion(nn.Module):
         fn.engine().ensure_packed(device, check_values=True)
         pack_id = fn.engine().pack_id
         key = (tuple(shape), str(device), self.noise_source, pack_id, bool(self.use_dynamic_thres),
-               float(self.dynamic_thres_percentile))
+               float(self.dynamic_thres_percentile), bool(self.pipeline_parts))
         if key in self._graphs:
             return self._graphs[key]
         for old in [k for k in self._graphs if k[0] != "cond" and k[3] != pack_id]:      # graphs over weights repacked since
@@ -263,9 +308,39 @@ class GaussianDiffusion(nn.Module):
             step()
         plan.self_advancing = self_advancing
         plan.step_counter = tcount          # the captured kernel counts in it at every replay: it lives as long as the plan
+        parts = getattr(plan, "parts", None)
+        if self_advancing and self.pipeline_parts and isinstance(parts, list) and len(parts) > 1:
+            graph = self._staggered_steps(plan, rng, device)
         runner = (graph, plan)
         self._graphs[key] = runner
         return runner
+
+    def _staggered_steps(self, plan, rng, device):
+        """The sub-batch plans of a SplitPlan as independent loops: one captured graph per part (its forward, then the
+        posterior step of its samples, which also counts its t down), each replayed on a stream of its own with nothing
+        joining them between steps."""
+        graphs, streams, keep = [], [], []
+        first = 0
+        for part in plan.parts:
+            n = part.x_in.shape[0]
+            tcount = torch.zeros(1, device=device, dtype=torch.int32)
+            stream = torch.cuda.Stream(device=device)
+
+            def step(part=part, tcount=tcount, first=first):
+                part.run(fork=False)
+                self.ddpm_step(part.x_in, part.eps_out, part.t_in, noise=None, clip_denoised=True, out=part.x_in,
+                               rng_state=rng, advance_t=tcount, batch_slice=(plan.B, first))
+
+            stream.wait_stream(torch.cuda.current_stream(device))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                step()
+            graphs.append(g)
+            streams.append(stream)
+            keep.append(tcount)
+            first += n
+        torch.cuda.synchronize(device)
+        return _StaggeredSteps(graphs, streams, keep, device, self.pipeline_stagger_s)
 
     @torch.inference_mode()
     def p_sample_loop(self, shape, x_T=None, noises=None, cond=None, cond_scale=1.):
@@ -290,10 +365,14 @@ class GaussianDiffusion(nn.Module):
             graph, plan = runner
             plan.x_in.copy_(img)
             plan.t_in.fill_(self.num_timesteps - 1)
+            if isinstance(graph, _StaggeredSteps):
+                graph.begin()
             for i in reversed(range(0, self.num_timesteps)):
                 if not plan.self_advancing:
                     plan.t_in.fill_(i)
                 graph.replay()      # (a self-advancing step leaves t at i - 1 for the next replay)
+            if isinstance(graph, _StaggeredSteps):
+                graph.finish()
             return plan.x_in.clone()
         for k, i in enumerate(reversed(range(0, self.num_timesteps))):
             t = torch.full((b,), i, device=device, dtype=torch.long)
