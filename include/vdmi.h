@@ -211,7 +211,9 @@ int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64_t rows_per
  * until the process ends); the call allocates and frees nothing.  Inputs that need more than that, i.e.
  * vdmi_groupnorm_workspace_bytes(nsamples, rows_per_sample, c) > VDMI_GROUPNORM_NOALLOC_SCRATCH_BYTES, are rejected with
  * VDMI_E_SCRATCH.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
- * threads) race; calls on one stream do not. */
+ * threads) race; calls on one stream do not.  The FIRST call on each GPU looks the array's address up
+ * (hipGetSymbolAddress, not a stream operation): make it once, eagerly, before capturing the call into a HIP graph;
+ * later calls are stream operations only.  `stream` must belong to the current device (VDMI_E_ARG otherwise). */
 #define VDMI_GROUPNORM_NOALLOC_SCRATCH_BYTES (1 << 20)
 int vdmi_groupnorm_silu_noalloc(const void* x, void* out, int nsamples, int64_t rows_per_sample, int c, int groups,
                                 const float* gamma, const float* beta, float eps, vdmi_stream stream);
@@ -486,7 +488,8 @@ int vdmi_conv_wgrad_gather(const void* xT, const void* dyT, float* dw, int cin, 
  * y: the convolution's output rows [batch*rows_per_batch][ldy] (what the forward normalised), dh: gradient of h;
  * writes dy (gradient of y) and accumulates dgamma [c], dbias [c] (= column sums of dy, the convolution's bias
  * gradient; may be NULL), dscale / dshift [batch][c] (NULL when scale / shift are NULL: a block without a time
- * embedding).  scale / shift: float [batch][sstride].  c: a power of two in 64..2048. */
+ * embedding).  scale / shift: float [batch][sstride].  c: a power of two in 64..2048.  The accumulated outputs are
+ * added across workgroups with float atomics: their last bits differ from run to run (dy is reproducible). */
 int vdmi_rmsnorm_silu_bwd(const void* y, int ldy, const void* dh, int ldh, void* dy, int lddy, int batch,
                           int64_t rows_per_batch, int c, const float* gamma, const float* scale, const float* shift,
                           int64_t sstride, float norm_scale, float* dgamma, float* dbias, float* dscale, float* dshift,

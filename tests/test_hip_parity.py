@@ -694,6 +694,34 @@ def test_vae_decode_vs_reference():
     assert rel_err(y.cpu(), g["decode"]) < MODEL_TOL
 
 
+def test_vae_plans_follow_weight_rewrites_without_a_per_call_fingerprint():
+    """Writes through `.data` move neither pointer nor version counter: a bare decode keeps serving the packed copy (it
+    does not synchronise to look at values), `VAE.weights_changed()` and the once-per-sample `check_values` - whose
+    fingerprint is position-sensitive: a sign flip keeps every norm - rebuild the plans; ordinary in-place updates
+    (optimizer steps, load_state_dict) are seen per call through the version counters."""
+    from video_diffusion_amd import VAE
+    from video_diffusion_amd.vae import check_values
+    from oracle import weightgen
+    vae = VAE(channels=3, latent_dim=4, base_dim=64)
+    vae.load_state_dict(weightgen.fill_state_dict(vae.state_dict(), 7))
+    vae = vae.to(dev()).eval()
+    z = inp("vae.z2", (1, 4, 2, 4, 4)).to(dev())
+    with torch.no_grad():
+        y0 = vae.decode(z)
+        w = vae.decoder.decoder[0].weight
+        w.data.neg_()                                   # same L1 / L2 norm, same pointer, same version
+        y_stale = vae.decode(z)
+        assert torch.equal(y_stale, y0)                 # no value check on the per-call path
+        check_values(vae)                               # what GaussianDiffusion.sample() runs once per call
+        y1 = vae.decode(z)
+        assert not torch.equal(y1, y0)
+        w.data.neg_()
+        vae.weights_changed()                           # the explicit form
+        assert torch.equal(vae.decode(z), y0)
+        w.mul_(0.5)                                     # an ordinary in-place update advances the version counter
+        assert not torch.equal(vae.decode(z), y0)
+
+
 def test_vae_encode_vs_reference():
     """VAEEncoder on the HIP library against the reference VAE's own mean / logvar (tests/golden/vae_tiny.npz)."""
     from video_diffusion_amd import VAE

@@ -55,6 +55,14 @@ def test_engine_generation_and_fingerprint_notice_data_writes():
     p.data.mul_(1.5)
     assert eng._param_key("cpu") == k0            # the blind spot
     assert eng._values_key() != v0                # what the sampling loops check once per loop
+    v1 = eng._values_key()
+    p.data.neg_()                                 # norm-preserving rewrites: a sign flip, two rows swapped
+    assert eng._values_key() != v1
+    p.data.neg_()
+    assert eng._values_key() == v1
+    first, second = p.data[0].clone(), p.data[1].clone()
+    p.data[0], p.data[1] = second, first
+    assert eng._values_key() != v1
     m._engine = eng
     m.weights_changed()
     assert eng._param_key("cpu") != k0            # what EMA / callers trigger explicitly

@@ -61,3 +61,30 @@ def test_noalloc_groupnorm_rejects_oversized_input():
                                          1e-5, torch.cuda.current_stream().cuda_stream)
     assert st == -6
     assert b"scratch" in lib.vdmi_strerror(st)
+
+
+def test_noalloc_groupnorm_under_graph_capture():
+    """What the entry point is for: after one eager call on the device (the address lookup), the call is captured
+    into a graph and replayed on new input; the replay equals the workspace variant bit for bit."""
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    nsamples, rows, c, groups = 2, 1500, 128, 8
+    x = (torch.randn(nsamples * rows, c, generator=g)).to(torch.bfloat16).to(dev)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+    st, _ = _run("noalloc", x, gamma, beta, nsamples, rows, c, groups, False)       # eager first call
+    assert st == 0
+    out = torch.empty_like(x)
+    status = []
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        status.append(lib.vdmi_groupnorm_silu_noalloc(x.data_ptr(), out.data_ptr(), nsamples, rows, c, groups,
+                                                      gamma.data_ptr(), beta.data_ptr(), 1e-5,
+                                                      torch.cuda.current_stream().cuda_stream))
+    assert status == [0]
+    x.copy_((torch.randn(nsamples * rows, c, generator=g) * 2.0).to(torch.bfloat16))
+    graph.replay()
+    torch.cuda.synchronize()
+    st, want = _run("ws", x, gamma, beta, nsamples, rows, c, groups, True)
+    assert st == 0 and torch.equal(out, want)

@@ -965,13 +965,20 @@ extern "C" int vdmi_groupnorm_silu(const void* x, void* out, int nsamples, int64
 // ------------------------------------------------------------------------------------------
 static __device__ __align__(256) float vdmi_gn_scratch[VDMI_GROUPNORM_NOALLOC_SCRATCH_BYTES / sizeof(float)];
 
-static float* gn_scratch_device_ptr(int* status) {
+static float* gn_scratch_device_ptr(hipStream_t stream, int* status) {
     static std::mutex mu;
     static float* ptr_of_device[64] = {nullptr};
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *status = VDMI_E_LAUNCH; return nullptr; }
+    // the array that is handed out is the current device's: a stream of another GPU would write to the wrong copy
+    if (stream) {
+        hipDevice_t sdev;
+        if (hipStreamGetDevice(stream, &sdev) == hipSuccess && (int)sdev != dev) { *status = VDMI_E_ARG; return nullptr; }
+    }
     std::lock_guard<std::mutex> lock(mu);
     if (!ptr_of_device[dev]) {
+        // first call on this device: a runtime call that is not a stream operation (it may load the code object), so
+        // this one call must not happen while the caller's stream is being captured
         void* p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(vdmi_gn_scratch)) != hipSuccess || !p) { *status = VDMI_E_LAUNCH; return nullptr; }
         ptr_of_device[dev] = static_cast<float*>(p);
@@ -986,7 +993,7 @@ extern "C" int vdmi_groupnorm_silu_noalloc(const void* x, void* out, int nsample
     if (need == 0) return VDMI_E_SHAPE;
     if (need > (size_t)VDMI_GROUPNORM_NOALLOC_SCRATCH_BYTES) return VDMI_E_SCRATCH;
     int st = VDMI_OK;
-    float* scratch = gn_scratch_device_ptr(&st);
+    float* scratch = gn_scratch_device_ptr(static_cast<hipStream_t>(stream), &st);
     if (!scratch) return st;
     // the first pass overwrites every partial sum the second pass reads: nothing has to start at zero
     return vdmi_groupnorm(x, out, nsamples, rows_per_sample, c, groups, gamma, beta, eps, 1, nullptr, nullptr, 0, nullptr, 0,

@@ -582,6 +582,12 @@ class GaussianDiffusion(nn.Module):
         latent_size = self.image_size // 8
         latent_channels = self.vae.latent_dim
         shape = (batch_size, latent_channels, self.num_frames, latent_size, latent_size)
+        if device.type == "cuda":
+            # once per call: writes through `.data` into the VAE or the frame encoder since their plans were built
+            from .vae import check_values
+            for mod in (self.vae, self.frame_cond_encoder):
+                if isinstance(mod, nn.Module):
+                    check_values(mod)
         if exists(prev_frames) and exists(self.frame_cond_encoder):
             self.vae.eval()
             prev_normalized = (prev_frames * 2.0 - 1.0).clamp(-1, 1)

@@ -765,6 +765,21 @@ class SplitPlan:
                 p.run(fork=False)
 
 
+def values_fingerprint(params):
+    """Per tensor its L2 norm and its dot product with a fixed ramp (1 .. 2 over the flattened tensor), as one tuple of
+    host floats.  The ramp makes the fingerprint position-sensitive: sign flips, swapped or permuted rows and other
+    norm-preserving rewrites of a tensor change it.  One device->host copy: not for use under graph capture."""
+    ps = [p.detach() for p in params]
+    if not ps:
+        return ()
+    with torch.no_grad():
+        vals = list(torch._foreach_norm(ps, 2))
+        for p in ps:
+            flat = p.reshape(-1).float()
+            vals.append(torch.dot(flat, torch.linspace(1.0, 2.0, flat.numel(), device=flat.device)))
+        return tuple(torch.stack([v.double() for v in vals]).cpu().tolist())
+
+
 class UnetEngine:
     plan_class = Plan
 
@@ -794,16 +809,11 @@ class UnetEngine:
         self._generation += 1
 
     def _values_key(self):
-        """Fingerprint of the parameter VALUES (L1 and L2 norm of every tensor, two multi-tensor launches and one
+        """Fingerprint of the parameter VALUES (values_fingerprint below: a handful of launches per tensor and one
         device->host copy).  Version counters miss in-place writes through `.data` (`p.data.copy_`, `p.data.mul_`,
         the reference's EMA `ma.data = ...` when the allocator hands back the same pointer); the sampling loops,
         which run thousands of launches on the packed copy, check this once per loop."""
-        ps = [p.detach() for p in self.unet.parameters()]
-        if not ps:
-            return ()
-        with torch.no_grad():
-            n = torch._foreach_norm(ps, 1) + torch._foreach_norm(ps, 2)
-            return tuple(torch.stack([v.double() for v in n]).cpu().tolist())
+        return values_fingerprint(self.unet.parameters())
 
     def ensure_packed(self, device, check_values: bool = False):
         """check_values: also compare the parameter values' fingerprint with the packed copy's (costs a host

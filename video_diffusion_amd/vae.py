@@ -15,6 +15,23 @@ def _use_hip(module, x):
                               (x.requires_grad or any(p.requires_grad for p in module.parameters())))
 
 
+def weights_changed(module):
+    """Tell the HIP plans of `module` and of its sub-modules that weights were rewritten through `.data` (in-place writes
+    that neither move the tensor nor advance its version counter); everything else is noticed without this."""
+    for m in module.modules():
+        eng = getattr(m, "_hip_engine", None)
+        if eng is not None:
+            eng.invalidate()
+
+
+def check_values(module):
+    """Once per sampling call: compare the value fingerprints of the HIP plans under `module` with the live weights."""
+    for m in module.modules():
+        eng = getattr(m, "_hip_engine", None)
+        if eng is not None:
+            eng.check_values()
+
+
 def _engine(module, cls_name):
     if getattr(module, "_hip_engine", None) is None:
         from . import vae_engine
@@ -74,6 +91,9 @@ class VAE(nn.Module):
 
     def decode(self, z):
         return self.decoder(z)
+
+    def weights_changed(self):
+        weights_changed(self)
 
     def reparameterize(self, mean, logvar):
         std = torch.exp(0.5 * logvar)

@@ -232,19 +232,34 @@ class _ShapeCachedEngine:
         self.module = module
         self._plans: Dict[Tuple, object] = {}
         self._key = None
+        self._values = None
+        self._generation = 0
+
+    def invalidate(self):
+        """The module's weights were rewritten in a way the version counters do not see (through `.data`): plans and
+        packed weights are rebuilt at the next call."""
+        self._generation += 1
+
+    def check_values(self):
+        """Compare a fingerprint of the parameter values with the one taken when the plans were built and rebuild on a
+        difference.  One host synchronisation: called once per sampling call (GaussianDiffusion.sample), never per
+        encode / decode and never under graph capture."""
+        from .engine import values_fingerprint
+        vals = values_fingerprint(self.module.parameters())
+        if self._values is not None and vals != self._values:
+            self.invalidate()
+        self._values = vals
 
     def _plan(self, x: torch.Tensor):
         if x.device.type != "cuda":
             raise _lib.VdmiError("the HIP encoders need a GPU tensor")
-        # pointers and autograd versions, plus a fingerprint of the values themselves (L1 / L2 norm per tensor: two
-        # multi-tensor launches and one host copy per call): writes through `.data` do not advance a version counter
-        ps = [p.detach() for p in self.module.parameters()]
-        with torch.no_grad():
-            norms = tuple(torch.stack([v.double() for v in torch._foreach_norm(ps, 1) + torch._foreach_norm(ps, 2)]).cpu().tolist()) if ps else ()
-        key = (str(x.device), norms) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+        # per call: pointers and autograd version counters only (no device synchronisation, usable under capture once
+        # the plan exists); writes through `.data` are caught by check_values() / invalidate()
+        key = (str(x.device), self._generation) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
         if key != self._key:
             self._plans.clear()
             self._key = key
+            self._values = None
         B, _, F, H, W = x.shape
         plan = self._plans.get((B, F, H, W))
         if plan is None:
