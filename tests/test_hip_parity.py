@@ -708,7 +708,7 @@ def test_vae_plans_follow_weight_rewrites_without_a_per_call_fingerprint():
     z = inp("vae.z2", (1, 4, 2, 4, 4)).to(dev())
     with torch.no_grad():
         y0 = vae.decode(z)
-        w = vae.decoder.decoder[0].weight
+        w = vae.decoder.decoder[3].weight                 # the (1,3,3) conv: its taps are packed into MFMA fragment order
         w.data.neg_()                                   # same L1 / L2 norm, same pointer, same version
         y_stale = vae.decode(z)
         assert torch.equal(y_stale, y0)                 # no value check on the per-call path

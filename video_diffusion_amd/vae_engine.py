@@ -257,9 +257,12 @@ class _ShapeCachedEngine:
         # the plan exists); writes through `.data` are caught by check_values() / invalidate()
         key = (str(x.device), self._generation) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
         if key != self._key:
+            # (re)build: the weights are packed from the live values now, so this is also when their fingerprint is taken
+            # (a host copy, once per rebuild - never on the calls that find their plan)
+            from .engine import values_fingerprint
             self._plans.clear()
             self._key = key
-            self._values = None
+            self._values = values_fingerprint(self.module.parameters())
         B, _, F, H, W = x.shape
         plan = self._plans.get((B, F, H, W))
         if plan is None:
