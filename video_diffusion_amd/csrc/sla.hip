@@ -13,6 +13,7 @@
 //  pass 2  per 32-row chunk (one wave): LayerNorm -> Q projection -> softmax over the head's 32
 //          features (in-lane) -> y = W' q + bias + x.  Wq and the frame's W' live in LDS.
 #include "vdmi_common.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -356,8 +357,9 @@ inline uint16_t host_bf16(float f) { return vdmi_host_half_bits(f); }
 void sla_geometry(int frames, int hw, int* nparts, int* chunks, int* cpp) {
     (void)frames;
     *chunks = (hw + 31) / 32;
+    static const int cap = [] { const char* e = std::getenv("VDMI_SLA_PARTS"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
     int np = *chunks / 16;
-    if (np > 8) np = 8;
+    if (np > cap) np = cap;
     if (np < 1) np = 1;
     *cpp = (*chunks + np - 1) / np;
     *nparts = (*chunks + *cpp - 1) / *cpp;
