@@ -195,6 +195,25 @@ int vdmi_xattn_pack_kv(const void* kvrows, int ldkv, void* kvpack, int nlayers, 
 int vdmi_xattn_core(const void* q, int ldq, void* o, const void* kvpack_layer, int b, int64_t rows_per_sample,
                     int l, int heads, vdmi_stream stream);
 
+/* Training form of the same core (what loss.backward() derives for CrossAttention.forward, vdp.py:511-521, when the
+ * frame-conditioning layers are trained, vdp.py:1146-1161, 1451).  vdmi_xattn_pack_kv_train packs one layer's projected
+ * context rows into 2 * vdmi_xattn_kv_elems(1, b, l, heads) elements (the two operand forms of vdmi_xattn_pack_kv plus
+ * V with the feature order of the core's output and K transposed).  vdmi_xattn_core_train_fwd is vdmi_xattn_core over
+ * that pack and also writes lse float [b][heads][lse_stride] (lse_stride >= rows_per_sample): the log2-domain
+ * log-sum-exp of every (query, head).  vdmi_xattn_core_train_bwd takes the same q, the forward's o and lse, the
+ * gradient dout of o (same layout and feature order as o) and writes dq bf16 [b*rows_per_sample][heads*32] (gradient
+ * of the scaled q rows, natural feature order), dkv bf16 [b*l][lddkv] (gradients of the key columns, then of the value
+ * columns, of kvrows) and delta float [b][heads][lse_stride] (scratch).  `workspace`:
+ * vdmi_xattn_bwd_workspace_bytes() bytes (partial key / value gradients, added in a fixed order: reproducible). */
+int vdmi_xattn_pack_kv_train(const void* kvrows, int ldkv, void* kvpack, int b, int l, int heads, vdmi_stream stream);
+int vdmi_xattn_core_train_fwd(const void* q, int ldq, void* o, const void* kvpack_train, float* lse, int64_t lse_stride,
+                              int b, int64_t rows_per_sample, int l, int heads, vdmi_stream stream);
+size_t vdmi_xattn_bwd_workspace_bytes(int b, int64_t rows_per_sample, int l, int heads);               /* HOST */
+int vdmi_xattn_core_train_bwd(const void* q, int ldq, const void* o, const void* dout, const void* kvpack_train,
+                              const void* kvrows, int ldkv, const float* lse, float* delta, int64_t lse_stride,
+                              void* dq, void* dkv, int lddkv, int b, int64_t rows_per_sample, int l, int heads,
+                              void* workspace, vdmi_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(groups, c) + SiLU of the VAE (vdp.py:93-108, 130-143) over channels-last bf16 rows
  * [nsamples * rows_per_sample][c]: statistics per (sample, group) over the sample's rows and the

@@ -630,3 +630,109 @@ def test_long_frame_axis_falls_back_to_torch_ops_under_the_hip_backend():
     a, b = run(True), run(False)
     for u, v in zip(a, b):
         assert torch.equal(u, v)          # the same torch ops ran both times
+
+
+def _xattn_core_ref(q, kvrows, b, n, L, heads):
+    """q [b*n][hid] already scaled by scale * log2 e, kvrows [b*L][2*hid]: softmax over the L keys per head, natural feature
+    order; returns (o [b*n][hid], log2-domain lse [b][heads][n])."""
+    hid = heads * 32
+    qf = q.float().view(b, n, heads, 32).transpose(1, 2)
+    kf = kvrows.float()[:, :hid].reshape(b, L, heads, 32).transpose(1, 2)
+    vf = kvrows.float()[:, hid:].reshape(b, L, heads, 32).transpose(1, 2)
+    s2 = qf @ kf.transpose(-1, -2)                                  # log2 domain
+    lse2 = torch.logsumexp(s2 * 0.6931471805599453, dim=-1) / 0.6931471805599453
+    p = torch.exp2(s2 - lse2[..., None])
+    o = (p @ vf).transpose(1, 2).reshape(b * n, hid)
+    return o, lse2
+
+
+@pytest.mark.parametrize("b,n,L,heads", [(1, 64, 32, 2), (2, 100, 37, 4), (1, 1000, 300, 8), (2, 515, 1024, 8), (1, 4096, 64, 1)])
+def test_cross_attention_core_forward_backward_vs_torch(b, n, L, heads):
+    """vdmi_xattn_core_train_fwd / _bwd (CrossAttention.forward's softmax attention, vdp.py:511-521) against torch autograd
+    over the same bf16 operands: output, log-sum-exp, and the gradients of q and of the projected key / value rows."""
+    from video_diffusion_amd import _lib, train_hip as T
+    lib = _lib.lib()
+    hid = heads * 32
+    g = torch.Generator().manual_seed(n + L)
+    q = _bf(torch.randn(b * n, hid, generator=g) * 0.8).to(DEV)
+    kv = _bf(torch.randn(b * L, 2 * hid, generator=g)).to(DEV)
+    dout_nat = _bf(torch.randn(b * n, hid, generator=g)).to(DEV)
+    perm = T._stored_feature_order(hid, DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    pack = torch.empty(2 * lib.vdmi_xattn_kv_elems(1, b, L, heads), device=DEV, dtype=torch.bfloat16)
+    assert lib.vdmi_xattn_pack_kv_train(kv.data_ptr(), 2 * hid, pack.data_ptr(), b, L, heads, s) == 0
+    npad = (n + 31) // 32 * 32
+    o = torch.empty(b * n, hid, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(b, heads, npad, device=DEV)
+    assert lib.vdmi_xattn_core_train_fwd(q.data_ptr(), hid, o.data_ptr(), pack.data_ptr(), lse.data_ptr(), npad, b, n, L, heads, s) == 0
+    # the plain core over the two-form pack gives the same output bits
+    pack2 = torch.empty(lib.vdmi_xattn_kv_elems(1, b, L, heads), device=DEV, dtype=torch.bfloat16)
+    o2 = torch.empty_like(o)
+    assert lib.vdmi_xattn_pack_kv(kv.data_ptr(), 2 * hid, pack2.data_ptr(), 1, b, L, heads, s) == 0
+    assert lib.vdmi_xattn_core(q.data_ptr(), hid, o2.data_ptr(), pack2.data_ptr(), b, n, L, heads, s) == 0
+    assert torch.equal(o, o2)
+
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    o_ref, lse_ref = _xattn_core_ref(qr, kvr, b, n, L, heads)
+    o_nat = torch.empty_like(o)
+    o_nat[:, perm] = o                                   # stored column c holds feature perm[c]
+    tag = f"xattn_core.n{n}_L{L}_h{heads}"
+    assert record(tag + ".o", rel_err(o_nat.float(), o_ref), 6e-3) < 6e-3
+    assert record(tag + ".lse", rel_err(lse[:, :, :n], lse_ref), 1e-4) < 1e-4
+    o_ref.backward(dout_nat.float())
+
+    dout = dout_nat[:, perm].contiguous()                # what the out-projection's input gradient looks like: stored order
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    delta = torch.zeros(b, heads, npad, device=DEV)
+    ws = torch.empty(lib.vdmi_xattn_bwd_workspace_bytes(b, n, L, heads), device=DEV, dtype=torch.uint8)
+    st = lib.vdmi_xattn_core_train_bwd(q.data_ptr(), hid, o.data_ptr(), dout.data_ptr(), pack.data_ptr(), kv.data_ptr(), 2 * hid,
+                                       lse.data_ptr(), delta.data_ptr(), npad, dq.data_ptr(), dkv.data_ptr(), 2 * hid, b, n, L,
+                                       heads, ws.data_ptr(), s)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert record(tag + ".dq", rel_err(dq.float(), qr.grad), 2e-2) < 2e-2
+    assert record(tag + ".dk", rel_err(dkv.float()[:, :hid], kvr.grad[:, :hid]), 2e-2) < 2e-2
+    assert record(tag + ".dv", rel_err(dkv.float()[:, hid:], kvr.grad[:, hid:]), 2e-2) < 2e-2
+    dkv2 = torch.empty_like(kv)
+    assert lib.vdmi_xattn_core_train_bwd(q.data_ptr(), hid, o.data_ptr(), dout.data_ptr(), pack.data_ptr(), kv.data_ptr(), 2 * hid,
+                                         lse.data_ptr(), delta.data_ptr(), npad, dq.data_ptr(), dkv2.data_ptr(), 2 * hid, b, n, L,
+                                         heads, ws.data_ptr(), s) == 0
+    assert torch.equal(dkv, dkv2)                        # partial sums are added in a fixed order
+
+
+@pytest.mark.parametrize("c,f,h,w,L,cd", [(64, 3, 8, 8, 48, 512), (128, 2, 6, 5, 100, 64)])
+def test_cross_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w, L, cd):
+    """Residual(PreNorm(CrossAttention)) (vdp.py:480-528, 803-805): output and every gradient, including the context's,
+    against the torch ops of autograd.py."""
+    from video_diffusion_amd import autograd as A, train_hip as T
+    from video_diffusion_amd.modules import CrossAttention, PreNorm, Residual
+    torch.manual_seed(3)
+    layer = Residual(PreNorm(c, CrossAttention(c, context_dim=cd, heads=4, dim_head=32))).to(DEV)
+    with torch.no_grad():
+        layer.fn.norm.gamma.copy_(1 + 0.2 * torch.randn_like(layer.fn.norm.gamma))
+    g = torch.Generator().manual_seed(8)
+    b = 2
+    x = torch.randn(b, c, f, h, w, generator=g).to(DEV)
+    ctx = torch.randn(b, L, cd, generator=g).to(DEV)
+    dout = torch.randn(b, c, f, h, w, generator=g).to(DEV)
+
+    def run(fn):
+        xr, cr = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+        for p in layer.parameters():
+            p.grad = None
+        out = fn(layer, xr, cr)
+        out.backward(dout)
+        grads = {n: p.grad.clone() for n, p in layer.named_parameters()}
+        grads["x"], grads["context"] = xr.grad.clone(), cr.grad.clone()
+        return out.detach().float(), grads
+
+    out_ref, g_ref = run(A._cross_attention_ops)
+    assert T.cross_attention_fits(layer.fn.fn, ctx)
+    out_hip, g_hip = run(T.cross_attention)
+    tag = f"xattn_layer.c{c}"
+    assert record(tag + ".out", rel_err(out_hip, out_ref), 1e-2) < 1e-2
+    assert set(g_hip) == set(g_ref)
+    for name in sorted(g_ref):
+        assert g_hip[name].shape == g_ref[name].shape, name
+        assert record(f"{tag}.grad.{name}", rel_err(g_hip[name], g_ref[name]), 3e-2) < 3e-2, name

@@ -206,6 +206,10 @@ def _linear_attention_ops(res, x):
 
 
 def _cross_attention(res, x, ctx):
+    if _HIP_ATTN and x.is_cuda:
+        from .train_hip import cross_attention, cross_attention_fits      # forward and backward on the HIP kernels
+        if cross_attention_fits(res.fn.fn, ctx):
+            return cross_attention(res, x, ctx)
     return _torch_ops(lambda x: _cross_attention_ops(res, x, ctx), x)
 
 

@@ -44,24 +44,37 @@ __global__ __launch_bounds__(256) void xattn_ctx_kernel(const float* __restrict_
 
 // kv rows bf16 [b*l][ld] (per layer: hid K columns then hid V columns) -> operand fragments
 // [layer][b][K,V][head][key tile][k-step][64 lanes][8]; keys >= l are zero.  One thread per fragment piece.
+// kinds = 4 (training): two more operand forms follow K and V^T per sample - V as an A operand [key x feature] whose
+// contraction index runs over the features in the order the core kernel stores them (column 16*hh + r of a head holds
+// feature (r&3) + 8*(r>>2) + 4*hh), and K^T as an A operand [feature x key] with the keys in accumulator-row order.
 __global__ __launch_bounds__(256) void xattn_pack_kv_kernel(const __bf16* __restrict__ rows, int ld, __bf16* __restrict__ out,
-                                                            int nlayers, int b, int l, int heads, int nt, long long total) {
+                                                            int nlayers, int b, int l, int heads, int nt, long long total,
+                                                            int kinds) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int lane = (int)(i & 63), s = (int)((i >> 6) & 1);
     long long r = i >> 7;
     const int t = (int)(r % nt); r /= nt;
     const int head = (int)(r % heads); r /= heads;
-    const int kv = (int)(r & 1); r >>= 1;
+    const int kind = (int)(r % kinds); r /= kinds;
+    const int kv = (kind == 1 || kind == 2) ? 1 : 0;        // which half of the row: keys or values
     const int bi = (int)(r % b);
     const int layer = (int)(r / b);
     const int half = lane >> 5, l31 = lane & 31, hid = heads * 32;
     const long long col0 = (long long)layer * 2 * hid + (long long)kv * hid + head * 32;
     bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (kv == 0) {
+    if (kind == 0) {
         // K as the A operand [key x d]: this lane's key, features s*16 + 8*half .. +7
         const int key = t * 32 + l31;
         if (key < l) o = *reinterpret_cast<const bf16x8*>(rows + ((long long)bi * l + key) * ld + col0 + s * 16 + 8 * half);
+    } else if (kind == 2) {
+        // V as the A operand [key x stored column]: contraction index s*16 + 8*half + j = stored column 16*s + (8*half + j)
+        const int key = t * 32 + l31;
+        if (key < l) {
+            const __bf16* src = rows + ((long long)bi * l + key) * ld + col0 + 16 * half + 4 * s;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = src[(j & 3) + 8 * (j >> 2)];
+        }
     } else {
         // V^T as the A operand [d x key]: this lane's feature, keys in the accumulator-row order of the scores
 #pragma unroll
@@ -79,6 +92,9 @@ struct XCoreArgs {
     const __bf16* kv;       // this layer: [b][2][heads][nt][2][64][8]
     long long rows_per_sample;
     int ldq, heads, l, nt, groups_per_sample, blocks_per_sample;
+    int kinds;              // operand forms per sample in the pack: 2 (K, V^T) or 4 (the training pack)
+    float* lse;             // [b][heads][lse_stride] or null: log2-domain log-sum-exp of every (query, head) for the backward
+    long long lse_stride;
 };
 
 constexpr int XC_WAVES = 8;          // waves (= 32-query groups) per workgroup, all of one sample
@@ -108,8 +124,8 @@ __global__ __launch_bounds__(XC_WAVES * 64) void xattn_core_kernel(const XCoreAr
     auto prefetch = [&](int step) {
         const int head = step / nchunks, t0 = (step - head * nchunks) * XC_CH;
         const int cnt = min(XC_CH, a.nt - t0);
-        const __bf16* kb = a.kv + (((long long)(b * 2 + 0) * a.heads + head) * a.nt + t0) * 1024;
-        const __bf16* vb = a.kv + (((long long)(b * 2 + 1) * a.heads + head) * a.nt + t0) * 1024;
+        const __bf16* kb = a.kv + (((long long)(b * a.kinds + 0) * a.heads + head) * a.nt + t0) * 1024;
+        const __bf16* vb = a.kv + (((long long)(b * a.kinds + 1) * a.heads + head) * a.nt + t0) * 1024;
 #pragma unroll
         for (int p = 0; p < XC_PP; ++p) {
             const int idx = tid + p * (XC_WAVES * 64);
@@ -197,6 +213,7 @@ __global__ __launch_bounds__(XC_WAVES * 64) void xattn_core_kernel(const XCoreAr
             __bf16* op = a.o + grow * hid + head * 32 + half * 16;
             *reinterpret_cast<bf16x8*>(op) = acc_frag(o * inv, 0);
             *reinterpret_cast<bf16x8*>(op + 8) = acc_frag(o * inv, 1);
+            if (a.lse && half == 0) a.lse[((long long)b * a.heads + head) * a.lse_stride + row] = m + __builtin_amdgcn_logf(lsum);
         }
     }
 }
@@ -219,23 +236,54 @@ extern "C" int vdmi_xattn_context(const float* ctx, const float* keep, void* row
     return VDMI_OK;
 }
 
+static int xattn_pack(const void* kvrows, int ldkv, void* kvpack, int nlayers, int b, int l, int heads, int kinds,
+                      vdmi_stream stream);
+
 extern "C" int vdmi_xattn_pack_kv(const void* kvrows, int ldkv, void* kvpack, int nlayers, int b, int l, int heads,
                                   vdmi_stream stream) {
+    return xattn_pack(kvrows, ldkv, kvpack, nlayers, b, l, heads, 2, stream);
+}
+
+// Training pack of one layer: 2 * vdmi_xattn_kv_elems(1, b, l, heads) elements, [b][K, V^T, V, K^T][head][tile][2][64][8].
+extern "C" int vdmi_xattn_pack_kv_train(const void* kvrows, int ldkv, void* kvpack, int b, int l, int heads,
+                                        vdmi_stream stream) {
+    return xattn_pack(kvrows, ldkv, kvpack, 1, b, l, heads, 4, stream);
+}
+
+static int xattn_pack(const void* kvrows, int ldkv, void* kvpack, int nlayers, int b, int l, int heads, int kinds,
+                      vdmi_stream stream) {
     if (!kvrows || !kvpack) return VDMI_E_ARG;
     if (nlayers <= 0 || b <= 0 || l <= 0 || heads <= 0 || ldkv < nlayers * 2 * heads * 32 || ldkv % 8) return VDMI_E_SHAPE;
     if (!aligned16(kvrows) || !aligned16(kvpack)) return VDMI_E_ALIGN;
     const int nt = (l + 31) / 32;
-    const long long total = (long long)nlayers * b * 2 * heads * nt * 128;
+    const long long total = (long long)nlayers * b * kinds * heads * nt * 128;
     if (total > 0x7fffffffLL * 256) return VDMI_E_SHAPE;
     hipLaunchKernelGGL(xattn_pack_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const __bf16*>(kvrows), ldkv,
-                       static_cast<__bf16*>(kvpack), nlayers, b, l, heads, nt, total);
+                       static_cast<__bf16*>(kvpack), nlayers, b, l, heads, nt, total, kinds);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
 
+static int xattn_core_launch(const void* q, int ldq, void* o, const void* kvpack_layer, int b, int64_t rows_per_sample,
+                             int l, int heads, int kinds, float* lse, int64_t lse_stride, vdmi_stream stream);
+
 extern "C" int vdmi_xattn_core(const void* q, int ldq, void* o, const void* kvpack_layer, int b, int64_t rows_per_sample,
                                int l, int heads, vdmi_stream stream) {
+    return xattn_core_launch(q, ldq, o, kvpack_layer, b, rows_per_sample, l, heads, 2, nullptr, 0, stream);
+}
+
+// The same core over a training pack (vdmi_xattn_pack_kv_train); also writes lse float [b][heads][lse_stride]
+// (lse_stride >= rows_per_sample): log2 of the softmax denominator plus the running maximum, in the log2 domain of q.
+extern "C" int vdmi_xattn_core_train_fwd(const void* q, int ldq, void* o, const void* kvpack_train, float* lse,
+                                         int64_t lse_stride, int b, int64_t rows_per_sample, int l, int heads,
+                                         vdmi_stream stream) {
+    if (!lse || lse_stride < rows_per_sample) return VDMI_E_ARG;
+    return xattn_core_launch(q, ldq, o, kvpack_train, b, rows_per_sample, l, heads, 4, lse, lse_stride, stream);
+}
+
+static int xattn_core_launch(const void* q, int ldq, void* o, const void* kvpack_layer, int b, int64_t rows_per_sample,
+                             int l, int heads, int kinds, float* lse, int64_t lse_stride, vdmi_stream stream) {
     if (!q || !o || !kvpack_layer) return VDMI_E_ARG;
     if (b <= 0 || rows_per_sample <= 0 || l <= 0 || heads <= 0 || ldq < heads * 32 || ldq % 8) return VDMI_E_SHAPE;
     if (!aligned16(q) || !aligned16(o) || !aligned16(kvpack_layer)) return VDMI_E_ALIGN;
@@ -248,6 +296,9 @@ extern "C" int vdmi_xattn_core(const void* q, int ldq, void* o, const void* kvpa
     a.heads = heads;
     a.l = l;
     a.nt = (l + 31) / 32;
+    a.kinds = kinds;
+    a.lse = lse;
+    a.lse_stride = lse_stride;
     const long long gps = (rows_per_sample + 31) / 32;
     const long long bps = (gps + XC_WAVES - 1) / XC_WAVES;
     if (gps > 0x7fffffffLL || bps * b > 0x7fffffffLL) return VDMI_E_SHAPE;

@@ -532,6 +532,112 @@ class TemporalAttnFn(torch.autograd.Function):
         return from_rows(dx, b, f, h, w, ctx.act), dgamma, dwqkv, dwout, dbias, None, None, None, None, None, None
 
 
+_LOG2E = 1.4426950408889634
+
+
+def _stored_feature_order(hid: int, device) -> torch.Tensor:
+    """Column 32*head + 16*hh + r of the cross-attention core's output holds feature 32*head + (r&3) + 8*(r>>2) + 4*hh."""
+    return torch.tensor([32 * hd + (r & 3) + 8 * (r >> 2) + 4 * hh for hd in range(hid // 32) for hh in (0, 1) for r in range(16)],
+                        device=device)
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """Residual(PreNorm(CrossAttention)) over x (B, C, F, H, W) and a context (B, L, D): vdp.py:380-389 (LayerNorm),
+    480-528 (CrossAttention.forward with heads of 32 features), 331-337 (Residual), forward and backward on the HIP
+    kernels.  gamma (1, C, 1, 1, 1); wq (heads*32, C); wk, wv (heads*32, D); wout (C, heads*32); bout (C)."""
+
+    @staticmethod
+    @_plain
+    def forward(ctx, x, context, gamma, wq, wk, wv, wout, bout, heads, scale, eps):
+        if not x.is_cuda:
+            raise _lib.VdmiError("the HIP training backend needs CUDA (HIP) tensors; there is no CPU path")
+        lib = _lib.lib()
+        b, c, f, h, w = x.shape
+        n, hid, L, cd = f * h * w, heads * 32, context.shape[1], context.shape[2]
+        rows = b * n
+        assert wq.shape == (hid, c) and wk.shape == (hid, cd) and wv.shape == (hid, cd) and wout.shape == (c, hid) and cd % 8 == 0
+        xr = to_rows(x)
+        xh = torch.empty_like(xr)
+        check(lib.vdmi_layernorm_rows(xr.data_ptr(), xh.data_ptr(), rows, c, eps, _stream()), "vdmi_layernorm_rows")
+        cs = scale * _LOG2E                     # the core exponentiates in the log2 domain
+        wq_eff = (wq.detach() * gamma.detach().reshape(1, c) * cs).contiguous()
+        q = conv_rows(xh, _linear_pack(wq_eff, False), None, b * f, f, h, w)
+        crow = context.detach().to(torch.bfloat16).reshape(b * L, cd).contiguous()
+        wkv = torch.cat((wk.detach(), wv.detach()), dim=0).contiguous()
+        kvrows = conv_rows(crow, _linear_pack(wkv, False), None, b, 1, 1, L)          # [b*L][K columns | V columns]
+        pack = torch.empty(2 * lib.vdmi_xattn_kv_elems(1, b, L, heads), device=x.device, dtype=torch.bfloat16)
+        check(lib.vdmi_xattn_pack_kv_train(kvrows.data_ptr(), 2 * hid, pack.data_ptr(), b, L, heads, _stream()),
+              "vdmi_xattn_pack_kv_train")
+        npad = (n + 31) // 32 * 32
+        o = torch.empty(rows, hid, device=x.device, dtype=torch.bfloat16)
+        lse = torch.zeros(b, heads, npad, device=x.device, dtype=torch.float32)
+        check(lib.vdmi_xattn_core_train_fwd(q.data_ptr(), hid, o.data_ptr(), pack.data_ptr(), lse.data_ptr(), npad, b, n, L,
+                                            heads, _stream()), "vdmi_xattn_core_train_fwd")
+        perm = _stored_feature_order(hid, x.device)
+        wout_p = wout.detach()[:, perm].contiguous()
+        y = conv_rows(o, _linear_pack(wout_p, False), None if bout is None else bout.detach().float().contiguous(), b * f, f, h,
+                      w, residual=xr)
+        ctx.save_for_backward(xr, xh, q, crow, kvrows, pack, o, lse, wq_eff, wkv, wout_p, perm, wq, gamma)
+        ctx.meta = (b, c, f, h, w, heads, cs, eps, L, cd, npad, context.dtype)
+        ctx.act = _act_dtype(x)
+        return from_rows(y, b, f, h, w, ctx.act)
+
+    @staticmethod
+    @_plain
+    def backward(ctx, dy):
+        xr, xh, q, crow, kvrows, pack, o, lse, wq_eff, wkv, wout_p, perm, wq, gamma = ctx.saved_tensors
+        b, c, f, h, w, heads, cs, eps, L, cd, npad, ctx_dtype = ctx.meta
+        lib = _lib.lib()
+        n, hid, frames = f * h * w, heads * 32, b * f
+        rows = b * n
+        need = ctx.needs_input_grad
+        dyr = to_rows(dy)
+        do = conv_rows(dyr, _linear_pack(wout_p, True), None, frames, f, h, w)          # stored feature order, like o
+        dwout = dbout = None
+        if need[6]:
+            dwout = torch.empty(c, hid, device=dy.device, dtype=torch.float32)
+            dwout[:, perm] = rows_wgrad(o, dyr)
+        if need[7]:
+            dbout = colsum_rows(dyr)
+        dq = torch.empty(rows, hid, device=dy.device, dtype=torch.bfloat16)
+        dkv = torch.empty(b * L, 2 * hid, device=dy.device, dtype=torch.bfloat16)
+        delta = torch.zeros(b, heads, npad, device=dy.device, dtype=torch.float32)
+        ws = torch.empty(lib.vdmi_xattn_bwd_workspace_bytes(b, n, L, heads), device=dy.device, dtype=torch.uint8)
+        check(lib.vdmi_xattn_core_train_bwd(q.data_ptr(), hid, o.data_ptr(), do.data_ptr(), pack.data_ptr(), kvrows.data_ptr(),
+                                            2 * hid, lse.data_ptr(), delta.data_ptr(), npad, dq.data_ptr(), dkv.data_ptr(),
+                                            2 * hid, b, n, L, heads, ws.data_ptr(), _stream()), "vdmi_xattn_core_train_bwd")
+        # to_q (with the folded gamma and scale), LayerNorm, residual
+        dxh = conv_rows(dq, _linear_pack(wq_eff, True), None, frames, f, h, w)
+        dwq = dgamma = None
+        if need[2] or need[3]:
+            dwe = rows_wgrad(xh, dq)
+            dwq = dwe * (gamma.detach().reshape(1, c) * cs)
+            dgamma = (dwe * wq.detach() * cs).sum(0).reshape(gamma.shape)
+        dx = torch.empty_like(xr)
+        check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
+                                          _stream()), "vdmi_layernorm_rows_bwd")
+        # to_k / to_v and the context
+        dctx = dwk = dwv = None
+        if need[1]:
+            dctx = conv_rows(dkv, _linear_pack(wkv, True), None, b, 1, 1, L).view(b, L, cd).to(ctx_dtype)
+        if need[4] or need[5]:
+            dwkv = rows_wgrad(crow, dkv)
+            dwk, dwv = dwkv[:hid].contiguous(), dwkv[hid:].contiguous()
+        return from_rows(dx, b, f, h, w, ctx.act), dctx, dgamma, dwq, dwk, dwv, dwout, dbout, None, None, None
+
+
+def cross_attention_fits(ca, context) -> bool:
+    """Heads of 32 features and a context width the row kernels take."""
+    return ca.to_q.out_features == ca.heads * 32 and context.shape[2] % 8 == 0 and ca.to_q.in_features % 8 == 0
+
+
+def cross_attention(res, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+    """autograd.py's `_cross_attention` on the HIP kernels."""
+    ca = res.fn.fn
+    return CrossAttnFn.apply(x, context, res.fn.norm.gamma, ca.to_q.weight, ca.to_k.weight, ca.to_v.weight, ca.to_out.weight,
+                             ca.to_out.bias, ca.heads, float(ca.scale), float(res.fn.norm.eps))
+
+
 def attention_core_fits(n_tok: int, heads: int, with_bias: bool) -> bool:
     """Whether the attention core kernels (forward AND backward, the latter with the bias-gradient table [heads][n][n] in
     LDS when the layer has a relative position bias) take a token axis of n_tok positions: 8 heads with a bias end near
