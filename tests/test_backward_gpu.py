@@ -736,3 +736,52 @@ def test_cross_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w, L,
     for name in sorted(g_ref):
         assert g_hip[name].shape == g_ref[name].shape, name
         assert record(f"{tag}.grad.{name}", rel_err(g_hip[name], g_ref[name]), 3e-2) < 3e-2, name
+
+
+def test_unet_backward_with_frame_conditioning_on_the_hip_kernels():
+    """A training step's loss.backward() with previous-frame conditioning (vdp.py:1146-1161 with frame_cond_features, the
+    CrossAttention layers of vdp.py:803-805, 824-826): loss, the gradient of the conditioning features (what trains the
+    FrameConditioningEncoder) and all parameter gradients, "hip" backend against the all-torch backend; the
+    cross-attention layers run on the library (none falls back)."""
+    from tests.helpers import inp, make_unet
+    from video_diffusion_amd import train_hip as T
+    m = make_unet(salt=2, dim=64, dim_mults=(1, 2), channels=3).to(DEV)
+    assert m.has_frame_cross_attn
+    x = inp("bwdfc.x", (2, 3, 4, 16, 16)).to(DEV)
+    noise = inp("bwdfc.noise", (2, 3, 4, 16, 16)).to(DEV)
+    feats = inp("bwdfc.feat", (2, 40, 512)).to(DEV)
+    t = torch.tensor([17, 203], device=DEV)
+    calls = []
+    orig = T.CrossAttnFn.apply
+
+    def run(backend):
+        m.train_backend = backend
+        for p in m.parameters():
+            p.grad = None
+        fr = feats.clone().requires_grad_(True)
+        loss = F.mse_loss(m(x, t, frame_cond_features=fr), noise)
+        loss.backward()
+        m.train_backend = None
+        return loss.detach(), fr.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    l_ref, gf_ref, g_ref = run("torch-autograd")
+    T.cross_attention_calls = 0
+    orig_ca = T.cross_attention
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig_ca(*a, **k)
+    T.cross_attention = spy
+    try:
+        l_hip, gf_hip, g_hip = run("hip")
+    finally:
+        T.cross_attention = orig_ca
+    assert len(calls) == len(m.frame_cross_attns_down) + len(m.frame_cross_attns_up)
+    assert set(g_ref) == set(g_hip)
+    assert any("frame_cross_attns" in n for n in g_hip)
+    cat = lambda d: torch.cat([d[n].flatten() for n in sorted(d)])
+    xa = lambda d: torch.cat([d[n].flatten() for n in sorted(d) if "frame_cross_attns" in n])
+    assert record("unet_bwd_framecond.loss", abs(float(l_hip - l_ref)) / float(l_ref), 2e-2) < 2e-2
+    assert record("unet_bwd_framecond.features_grad", rel_err(gf_hip, gf_ref), 6e-2) < 6e-2
+    assert record("unet_bwd_framecond.cross_attn_param_grads", rel_err(xa(g_hip), xa(g_ref)), 6e-2) < 6e-2
+    assert record("unet_bwd_framecond.all_param_grads", rel_err(cat(g_hip), cat(g_ref)), 6e-2) < 6e-2

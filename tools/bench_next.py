@@ -128,24 +128,32 @@ def train_step(args, dev):
     x = torch.randn(B, args.train_channels, args.train_frames, args.train_size, args.train_size, device=dev)
     noise = torch.randn_like(x)
     t = torch.randint(0, 1000, (B,), device=dev)
+    # --train-context L: previous-frame conditioning features (B, L, 512), i.e. the eight CrossAttention layers in the step
+    feats = torch.randn(B, args.train_context, 512, device=dev, requires_grad=True) if args.train_context else None
 
     def step(backend, amp):
         unet.train_backend = backend
         for p in unet.parameters():
             p.grad = None
+        if feats is not None:
+            feats.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            loss = F.l1_loss(unet(x, t).float(), noise)
+            eps = unet(x, t) if feats is None else unet(x, t, frame_cond_features=feats)
+            loss = F.l1_loss(eps.float(), noise)
         loss.backward()
         return loss
 
     out = {"workload": f"training step: Unet3D(dim={args.train_dim}, channels={args.train_channels}) p_losses forward + backward on {tuple(x.shape)}, "
-                       "random-init weights, no optimizer step", "ms_per_step": {}, "loss": {}, "peak_mem_gib": {}}
+                       "random-init weights, no optimizer step" + (f", frame conditioning on {args.train_context} context tokens" if args.train_context else ""),
+           "ms_per_step": {}, "loss": {}, "peak_mem_gib": {}}
     runs = (("hip + bf16 autocast of the torch layers", "hip", True), ("hip", "hip", False),
             ("hip-resnet", "hip-resnet", False), ("hip-resnet + bf16 autocast of the torch layers", "hip-resnet", True),
             ("torch-autograd bf16 autocast", "torch-autograd", True),
             ("torch-autograd fp32", "torch-autograd", False))
     if args.train_backends:
         runs = tuple(r for r in runs if r[0].split()[0] in args.train_backends.split(","))
+    if args.train_amp_only:
+        runs = tuple(r for r in runs if r[2])
     for name, backend, amp in runs:
         torch.cuda.reset_peak_memory_stats()
         try:
@@ -210,6 +218,8 @@ def main():
     ap.add_argument("--train-size", type=int, default=128)
     ap.add_argument("--train-dim", type=int, default=128)
     ap.add_argument("--train-frames", type=int, default=16)
+    ap.add_argument("--train-amp-only", action="store_true", help="skip the runs whose torch layers compute in fp32")
+    ap.add_argument("--train-context", type=int, default=0, help="context tokens of previous-frame conditioning (0: none)")
     ap.add_argument("--train-channels", type=int, default=3)
     ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--train-profile-backend", default="hip")
