@@ -539,17 +539,19 @@ int vdmi_layernorm_rows_bwd(const void* x, const void* dxh, const void* add, voi
  * 256 threads and the LDS hold.  With hw = 1 the "frames" of a site are f consecutive rows: the mid-block spatial
  * attention over the positions of a frame (vdp.py:708-710; b = frames, f = positions, no rotary, no bias).
  * Backward: from qkv, o, lse and dout (gradient of o) the gradient of the raw qkv rows (dqkv, same layout) and of the
- * bias (dbias float [heads][f][f], ACCUMULATED; may be NULL). */
+ * bias (dbias float [heads][f][f], ACCUMULATED; may be NULL).  focus: uint8 [b] or NULL - the focus-present mask of
+ * vdp.py:590-600: in a flagged sample every frame attends to itself only (scores off the diagonal are masked). */
 /* HOST. 1 when vdmi_tattn_core_fwd (bwd = 0) / vdmi_tattn_core_bwd (bwd = 1; with_dbias: a relative-position-bias
  * gradient is asked for) can run a token axis of f positions with `heads` heads: the site's tiles and, in the
  * backward, the bias-gradient table [heads][f][f] must fit 160 KiB of LDS (with 8 heads the backward ends near
  * f = 62), and f <= 256.  Callers fall back to torch ops for longer axes. */
 int vdmi_tattn_core_fits(int bwd, int f, int heads, int with_dbias);
 int vdmi_tattn_core_fwd(const void* qkv, void* o, float* lse, const float* bias, const float* rot_cos,
-                        const float* rot_sin, int b, int f, int hw, int heads, float scale, vdmi_stream stream);
+                        const float* rot_sin, const uint8_t* focus, int b, int f, int hw, int heads, float scale,
+                        vdmi_stream stream);
 int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* dbias,
-                        const float* bias, const float* rot_cos, const float* rot_sin, int b, int f, int hw, int heads,
-                        float scale, vdmi_stream stream);
+                        const float* bias, const float* rot_cos, const float* rot_sin, const uint8_t* focus, int b, int f,
+                        int hw, int heads, float scale, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training kernels of Residual(PreNorm(SpatialLinearAttention)) (vdp.py:454-479), forward and backward, on the RAW rows of

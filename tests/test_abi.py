@@ -215,11 +215,11 @@ def test_attention_training_entry_points_reject_bad_arguments():
     assert lib.vdmi_layernorm_rows(16, 16, 10, 96, 1e-5, None) == E_SHAPE                       # not a power of two
     assert lib.vdmi_layernorm_rows(16, 24, 10, 64, 1e-5, None) == E_ALIGN
     assert lib.vdmi_layernorm_rows_bwd(16, None, None, 16, 10, 64, 1e-5, None) == E_ARG
-    assert lib.vdmi_tattn_core_fwd(None, 16, 16, None, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG
-    assert lib.vdmi_tattn_core_fwd(16, 16, 16, None, None, None, 1, 257, 64, 8, 0.17, None) == E_SHAPE   # f > 256
-    assert lib.vdmi_tattn_core_fwd(16, 16, 16, None, 16, None, 1, 10, 64, 8, 0.17, None) == E_ARG        # cos without sin
-    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, 16, None, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG   # dbias, no bias
-    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, None, None, None, None, 1, 300, 64, 8, 0.17, None) == E_SHAPE  # f > 256
+    assert lib.vdmi_tattn_core_fwd(None, 16, 16, None, None, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG
+    assert lib.vdmi_tattn_core_fwd(16, 16, 16, None, None, None, None, 1, 257, 64, 8, 0.17, None) == E_SHAPE   # f > 256
+    assert lib.vdmi_tattn_core_fwd(16, 16, 16, None, 16, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG        # cos without sin
+    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, 16, None, None, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG   # dbias, no bias
+    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, None, None, None, None, None, 1, 300, 64, 8, 0.17, None) == E_SHAPE  # f > 256
     assert lib.vdmi_sla_train_partial_bytes(16, 4096, 4) == 16 * 4 * 4 * (1024 + 64) * 4
     assert lib.vdmi_sla_train_combined_bytes(16, 4) == 16 * 4 * (1024 + 64) * 4
     assert lib.vdmi_sla_train_partial_bytes(16, 4096, 3) == 0                                   # 256 % heads

@@ -264,8 +264,9 @@ def test_layernorm_rows_forward_backward_vs_torch(c, rows):
     assert record(f"layernorm.c{c}.bwd", rel_err(dx.float().cpu(), (xr.grad + add.double()).cpu()), 5e-3) < 5e-3
 
 
-def _attn_core_ref(qkv, bias, cos, sin, b, f, hw, heads, scale):
-    """Attention over frames on raw q, k, v rows (vdp.py:560-606), double precision torch ops."""
+def _attn_core_ref(qkv, bias, cos, sin, b, f, hw, heads, scale, focus=None):
+    """Attention over frames on raw q, k, v rows (vdp.py:560-606), double precision torch ops; focus: bool [b], the
+    focus-present mask of vdp.py:590-600."""
     hid = heads * 32
     t = qkv.view(b, f, hw, 3, heads, 32).permute(3, 0, 2, 4, 1, 5)            # [3][b][hw][heads][f][32]
     q, k, v = t[0] * scale, t[1], t[2]
@@ -280,14 +281,18 @@ def _attn_core_ref(qkv, bias, cos, sin, b, f, hw, heads, scale):
     sim = rot(q) @ rot(k).transpose(-1, -2)
     if bias is not None:
         sim = sim + bias
+    if focus is not None:
+        keep = torch.eye(f, device=sim.device, dtype=torch.bool).view(1, 1, 1, f, f) | ~focus.view(-1, 1, 1, 1, 1)
+        sim = sim.masked_fill(~keep, -torch.finfo(sim.dtype).max)
     out = sim.softmax(-1) @ v                                                  # [b][hw][heads][f][32]
     return out.permute(0, 3, 1, 2, 4).reshape(b * f * hw, hid)
 
 
-@pytest.mark.parametrize("b,f,hw,heads,rotary,with_bias", [(2, 10, 37, 8, True, True), (1, 16, 64, 8, True, True),
-                                                           (3, 5, 20, 4, False, False), (1, 32, 9, 8, True, True),
-                                                           (3, 256, 1, 8, False, False), (2, 64, 1, 8, False, False)])
-def test_tattn_core_forward_backward_vs_torch(b, f, hw, heads, rotary, with_bias):
+@pytest.mark.parametrize("b,f,hw,heads,rotary,with_bias,focus", [
+    (2, 10, 37, 8, True, True, None), (1, 16, 64, 8, True, True, None), (3, 5, 20, 4, False, False, None),
+    (1, 32, 9, 8, True, True, None), (3, 256, 1, 8, False, False, None), (2, 64, 1, 8, False, False, None),
+    (3, 10, 37, 8, True, True, (True, False, True)), (2, 6, 16, 4, False, True, (True, True))])
+def test_tattn_core_forward_backward_vs_torch(b, f, hw, heads, rotary, with_bias, focus):
     from video_diffusion_amd import _lib
     lib = _lib.lib()
     g = torch.Generator().manual_seed(10)
@@ -301,17 +306,18 @@ def test_tattn_core_forward_backward_vs_torch(b, f, hw, heads, rotary, with_bias
     ptr = lambda t: None if t is None else t.data_ptr()
     o = torch.empty(rows, hid, device=DEV, dtype=torch.bfloat16)
     lse = torch.empty(rows, heads, device=DEV)
-    _lib.check(lib.vdmi_tattn_core_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ptr(bias), ptr(cos), ptr(sin), b, f, hw,
-                                       heads, scale, None))
+    foc = None if focus is None else torch.tensor(focus, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.vdmi_tattn_core_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ptr(bias), ptr(cos), ptr(sin), ptr(foc),
+                                       b, f, hw, heads, scale, None))
     dqkv = torch.empty_like(qkv)
     dbias = torch.zeros_like(bias) if with_bias else None
     _lib.check(lib.vdmi_tattn_core_bwd(qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                       ptr(dbias), ptr(bias), ptr(cos), ptr(sin), b, f, hw, heads, scale, None))
+                                       ptr(dbias), ptr(bias), ptr(cos), ptr(sin), ptr(foc), b, f, hw, heads, scale, None))
     qr = qkv.double().requires_grad_(True)
     br = bias.double().requires_grad_(True) if with_bias else None
-    ref = _attn_core_ref(qr, br, cos, sin, b, f, hw, heads, scale)
+    ref = _attn_core_ref(qr, br, cos, sin, b, f, hw, heads, scale, None if foc is None else foc.bool())
     ref.backward(dout.double())
-    tag = f"tattn_core.f{f}.h{heads}"
+    tag = f"tattn_core.f{f}.h{heads}" + ("" if focus is None else ".focus")
     assert record(tag + ".o", rel_err(o.float().cpu(), ref.detach().cpu()), 5e-3) < 5e-3
     assert record(tag + ".dqkv", rel_err(dqkv.float().cpu(), qr.grad.cpu()), 1e-2) < 1e-2
     if with_bias:
@@ -350,6 +356,10 @@ def test_temporal_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w)
     with torch.no_grad():       # the module called on its own, with the reference's keyword
         assert torch.equal(res(x, pos_bias=bias0), out_hip)
         assert torch.equal(res(x, pos_bias=bias0, focus_present_mask=torch.zeros(2, dtype=torch.bool, device=DEV)), out_hip)
+        fm = torch.tensor([True, False], device=DEV)      # flagged sample: every frame attends to itself only
+        out_f = res(x, pos_bias=bias0, focus_present_mask=fm)
+        assert record(f"tattn_layer.c{c}.focus_out", rel_err(out_f, A._temporal(res, x, bias0, fm)), 2e-2) < 2e-2
+        assert torch.equal(out_f[1], out_hip[1]) and not torch.equal(out_f[0], out_hip[0])
     tag = f"tattn_layer.c{c}"
     assert record(tag + ".out", rel_err(out_hip, out_ref), 2e-2) < 2e-2
     assert set(g_hip) == set(g_ref)
@@ -500,8 +510,8 @@ def test_input_gradient_alone_skips_the_weight_gradients():
 
 def test_bf16_activation_stream_between_hip_layers():
     """A HIP layer answers a bf16 activation with a bf16 view of its own output rows (no cast, no copy on either side)
-    and a float one in float, with the same bits; a layer that falls back to torch ops inside the stream (here the
-    focus-masked temporal attention, vdp.py:590-600) is widened and narrowed around it, also outside autocast."""
+    and a float one in float, with the same bits; a whole model with focus-present flags (vdp.py:590-600: the flagged
+    samples' temporal attention is masked to the diagonal inside the attention core) trains on the same stream."""
     from tests.helpers import inp, make_unet
     from video_diffusion_amd import train_hip
     m = make_unet(salt=4, dim=64, dim_mults=(1, 2), channels=3).to(DEV)

@@ -140,9 +140,10 @@ def _core_fits(n_tok, heads, with_bias):
 def _temporal(res, x, pos_bias, focus=None):
     # Residual(PreNorm(EinopsToAndFrom('b c f h w', 'b (h w) f c', Attention))), vdp.py:636
     att = res.fn.fn.fn
-    if _HIP_ATTN and focus is None and x.is_cuda and _core_fits(x.shape[2], att.heads, pos_bias is not None):
+    if _HIP_ATTN and x.is_cuda and _core_fits(x.shape[2], att.heads, pos_bias is not None):
         from .train_hip import temporal_attention     # forward and backward on the HIP kernels
-        return temporal_attention(res, x, pos_bias, _rot_tables(getattr(att, "rotary_emb", None), x.shape[2], x.device))
+        return temporal_attention(res, x, pos_bias, _rot_tables(getattr(att, "rotary_emb", None), x.shape[2], x.device),
+                                  focus)
     return _torch_ops(lambda x: _temporal_ops(res, x, pos_bias, focus), x)
 
 

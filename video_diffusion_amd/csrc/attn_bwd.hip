@@ -112,6 +112,7 @@ struct CoreArgs {
     const float* bias;      // [heads][f][f] or null
     const float* rot_cos;   // [f][16] or null
     const float* rot_sin;
+    const unsigned char* focus;   // [b] or null: samples whose frames attend to themselves only (vdp.py:590-600)
     int b, f, hw, heads;
     int spw;                // sites per workgroup pass
     int hpw, hgroups;       // heads per workgroup pass, heads / hpw (long token axes leave room for few heads at a time)
@@ -237,6 +238,9 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
             lds_store32(Vl + slot * CORE_ROWF, v);
         }
         const float* bias_i = a.bias ? a.bias + ((long long)h * F + i) * F : nullptr;
+        // focus-present samples: every score off the diagonal is masked (its probability is an exact zero, so are its
+        // gradients; the diagonal's own gradient cancels: a softmax over one element is constant)
+        const bool foc = a.focus && valid && a.focus[bb] != 0;
         if constexpr (!BWD) {
             __syncthreads();
             if (valid) {
@@ -245,7 +249,8 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
                 for (int d = 0; d < 32; ++d) o[d] = 0.f;
                 for (int j = 0; j < F; ++j) {
                     const int sj = ((s * F + j) * HP + hl) * CORE_ROWF;
-                    const float sc = lds_dot32(Kl + sj, q) + (bias_i ? bias_i[j] : 0.f);
+                    float sc = lds_dot32(Kl + sj, q) + (bias_i ? bias_i[j] : 0.f);
+                    if (foc && j != i) sc = -1e30f;
                     const float mn = fmaxf(m, sc);
                     const float corr = __expf(m - mn), p = __expf(sc - mn);
                     l = l * corr + p;
@@ -285,8 +290,8 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
                     float kr[32];
                     lds_load32(Kl + sj, kr);
                     const float sc = dot32(kr, q) + (bias_i ? bias_i[j] : 0.f);
-                    const float p = __expf(sc - lse);
-                    const float ds = p * (lds_dot32(Vl + sj, g) - D);
+                    const float p = (foc && j != i) ? 0.f : __expf(sc - lse);
+                    const float ds = foc ? 0.f : p * (lds_dot32(Vl + sj, g) - D);      // one unmasked key: the softmax is constant
                     axpy32(kr, ds, dq);
                     if (a.dbias) atomicAdd(&Bl[(h * F + i) * F + j], ds);
                 }
@@ -305,8 +310,8 @@ __global__ __launch_bounds__(256) void tattn_core_kernel(const CoreArgs a) {
                     lds_load32(Ql + sq, qr);
                     lds_load32(Gl + sq, gr);
                     const float sc = dot32(qr, k) + bq;
-                    const float p = __expf(sc - Sl[2 * slq]);
-                    const float ds = p * (dot32(gr, v) - Sl[2 * slq + 1]);
+                    const float p = (foc && qi != i) ? 0.f : __expf(sc - Sl[2 * slq]);
+                    const float ds = foc ? 0.f : p * (dot32(gr, v) - Sl[2 * slq + 1]);
                     axpy32(qr, ds, dk);
                     axpy32(gr, p, dv);
                 }
@@ -414,21 +419,22 @@ extern "C" int vdmi_layernorm_rows_bwd(const void* x, const void* dxh, const voi
 }
 
 extern "C" int vdmi_tattn_core_fwd(const void* qkv, void* o, float* lse, const float* bias, const float* rot_cos,
-                                   const float* rot_sin, int b, int f, int hw, int heads, float scale, vdmi_stream stream) {
+                                   const float* rot_sin, const uint8_t* focus, int b, int f, int hw, int heads, float scale,
+                                   vdmi_stream stream) {
     if (!qkv || !o || !lse) return VDMI_E_ARG;
     if (!aligned16(qkv) || !aligned16(o)) return VDMI_E_ALIGN;
     CoreArgs a{};
     a.qkv = static_cast<const __bf16*>(qkv);
     a.out = static_cast<__bf16*>(o);
     a.lse_out = lse;
-    a.bias = bias; a.rot_cos = rot_cos; a.rot_sin = rot_sin;
+    a.bias = bias; a.rot_cos = rot_cos; a.rot_sin = rot_sin; a.focus = focus;
     a.b = b; a.f = f; a.hw = hw; a.heads = heads; a.scale = scale;
     return core_launch(false, a, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
-                                   float* dbias, const float* bias, const float* rot_cos, const float* rot_sin, int b, int f,
-                                   int hw, int heads, float scale, vdmi_stream stream) {
+                                   float* dbias, const float* bias, const float* rot_cos, const float* rot_sin,
+                                   const uint8_t* focus, int b, int f, int hw, int heads, float scale, vdmi_stream stream) {
     if (!qkv || !o || !dout || !lse || !dqkv) return VDMI_E_ARG;
     if (dbias && !bias) return VDMI_E_ARG;
     if (!aligned16(qkv) || !aligned16(o) || !aligned16(dout) || !aligned16(dqkv)) return VDMI_E_ALIGN;
@@ -439,7 +445,7 @@ extern "C" int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* d
     a.lse = lse;
     a.out = static_cast<__bf16*>(dqkv);
     a.dbias = dbias;
-    a.bias = bias; a.rot_cos = rot_cos; a.rot_sin = rot_sin;
+    a.bias = bias; a.rot_cos = rot_cos; a.rot_sin = rot_sin; a.focus = focus;
     a.b = b; a.f = f; a.hw = hw; a.heads = heads; a.scale = scale;
     return core_launch(true, a, static_cast<hipStream_t>(stream));
 }

@@ -91,7 +91,7 @@ class Residual(_HipOnly):
         """The two attention layers of a UNet level called on their own (reference vdp.py:331-337 around PreNorm):
         Residual(PreNorm(SpatialLinearAttention)) and the temporal Residual(PreNorm(EinopsToAndFrom(Attention))) run
         forward and backward on the HIP kernels (train_hip.py); x float (B, C, F, H, W) on the GPU.  The temporal layer
-        takes `pos_bias=` as in the reference; a focus_present_mask with any flag set is not served here."""
+        takes `pos_bias=` and `focus_present_mask=` (bool [B]) as in the reference."""
         pre = self.fn
         core = getattr(pre, "fn", None)
         if isinstance(pre, PreNorm) and isinstance(core, SpatialLinearAttention):
@@ -100,12 +100,13 @@ class Residual(_HipOnly):
         if (isinstance(pre, PreNorm) and isinstance(core, EinopsToAndFrom) and isinstance(core.fn, Attention)
                 and core.to_einops == 'b (h w) f c'):
             mask = kwargs.get("focus_present_mask")
-            if mask is not None and bool(torch.as_tensor(mask).any()):
-                return super().forward(x, *args, **kwargs)
+            if mask is not None and not bool(torch.as_tensor(mask).any()):
+                mask = None                     # vdp.py:590: the mask is skipped when nothing is flagged
             from . import autograd
             from .train_hip import temporal_attention
             rot = autograd._rot_tables(core.fn.rotary_emb, x.shape[2], x.device)
-            return temporal_attention(self, x, kwargs.get("pos_bias"), rot)
+            return temporal_attention(self, x, kwargs.get("pos_bias"), rot,
+                                      None if mask is None else torch.as_tensor(mask, device=x.device))
         if (isinstance(pre, PreNorm) and isinstance(core, EinopsToAndFrom) and isinstance(core.fn, Attention)
                 and core.to_einops == 'b f (h w) c' and core.fn.rotary_emb is None):
             from .train_hip import spatial_attention          # the mid-block attention over the positions of a frame

@@ -472,7 +472,7 @@ class TemporalAttnFn(torch.autograd.Function):
 
     @staticmethod
     @_plain
-    def forward(ctx, x, gamma, wqkv, wout, bias, cos, sin, heads, scale, eps, spatial=False):
+    def forward(ctx, x, gamma, wqkv, wout, bias, cos, sin, heads, scale, eps, spatial=False, focus=None):
         if not x.is_cuda:
             raise _lib.VdmiError("the HIP training backend needs CUDA (HIP) tensors; there is no CPU path")
         lib = _lib.lib()
@@ -490,10 +490,12 @@ class TemporalAttnFn(torch.autograd.Function):
         ptr = lambda t: None if t is None else t.data_ptr()
         # groups of the core: the f frames of a site (rows hw apart), or - spatial - the hw positions of a frame (consecutive rows)
         core = (b * f, hw, 1) if spatial else (b, f, hw)
-        check(lib.vdmi_tattn_core_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ptr(bias_c), ptr(cos), ptr(sin), *core,
-                                      heads, scale, _stream()), "vdmi_tattn_core_fwd")
+        # focus: bool / uint8 [b], samples whose frames attend to themselves only (the focus-present mask, vdp.py:590-600)
+        foc = None if (focus is None or spatial) else focus.detach().to(device=x.device, dtype=torch.uint8).contiguous()
+        check(lib.vdmi_tattn_core_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ptr(bias_c), ptr(cos), ptr(sin), ptr(foc),
+                                      *core, heads, scale, _stream()), "vdmi_tattn_core_fwd")
         y = conv_rows(o, _linear_pack(wout.detach().contiguous(), False), None, b * f, f, h, w, residual=xr)
-        ctx.save_for_backward(xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin)
+        ctx.save_for_backward(xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin, foc)
         ctx.meta = (b, c, f, h, w, heads, scale, eps, core)
         ctx.act = _act_dtype(x)
         return from_rows(y, b, f, h, w, ctx.act)
@@ -501,7 +503,7 @@ class TemporalAttnFn(torch.autograd.Function):
     @staticmethod
     @_plain
     def backward(ctx, dy):
-        xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin = ctx.saved_tensors
+        xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin, foc = ctx.saved_tensors
         b, c, f, h, w, heads, scale, eps, core = ctx.meta
         lib = _lib.lib()
         hw, rows, hid, frames = h * w, b * f * h * w, heads * 32, b * f
@@ -517,7 +519,7 @@ class TemporalAttnFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias_c) if (bias_c is not None and need[4]) else None
         check(lib.vdmi_tattn_core_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                      ptr(dbias), ptr(bias_c), ptr(cos), ptr(sin), *core, heads, scale, _stream()),
+                                      ptr(dbias), ptr(bias_c), ptr(cos), ptr(sin), ptr(foc), *core, heads, scale, _stream()),
               "vdmi_tattn_core_bwd")
         # to_qkv (with the folded gamma), LayerNorm, residual
         dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
@@ -529,7 +531,7 @@ class TemporalAttnFn(torch.autograd.Function):
         dx = torch.empty_like(xr)
         check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
                                           _stream()), "vdmi_layernorm_rows_bwd")
-        return from_rows(dx, b, f, h, w, ctx.act), dgamma, dwqkv, dwout, dbias, None, None, None, None, None, None
+        return from_rows(dx, b, f, h, w, ctx.act), dgamma, dwqkv, dwout, dbias, None, None, None, None, None, None, None
 
 
 _LOG2E = 1.4426950408889634
@@ -656,14 +658,14 @@ def spatial_attention(res, x: torch.Tensor) -> torch.Tensor:
                                 float(att.scale), float(res.fn.norm.eps), True)
 
 
-def temporal_attention(res, x: torch.Tensor, pos_bias, rot_tables) -> torch.Tensor:
-    """autograd.py's `_temporal` (no focus mask) on the HIP kernels.  rot_tables: (cos, sin) float [F][16] or None."""
+def temporal_attention(res, x: torch.Tensor, pos_bias, rot_tables, focus=None) -> torch.Tensor:
+    """autograd.py's `_temporal` on the HIP kernels.  rot_tables: (cos, sin) float [F][16] or None; focus: bool [B] or None."""
     att = res.fn.fn.fn
     if att.dim_head != 32:
         raise _lib.VdmiError("the HIP temporal attention takes heads of 32 features")
     cos, sin = rot_tables if rot_tables is not None else (None, None)
     return TemporalAttnFn.apply(x, res.fn.norm.gamma, att.to_qkv.weight, att.to_out.weight, pos_bias, cos, sin, att.heads,
-                                float(att.scale), float(res.fn.norm.eps))
+                                float(att.scale), float(res.fn.norm.eps), False, focus)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
