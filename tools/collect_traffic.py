@@ -32,8 +32,9 @@ def klass(name):
         return f"tapgemm<epi={m.group(6)},bn={m.group(2)}>"
     if "wsconv64_kernel" in name:
         return "wsconv64"
-    if "dconv_kernel" in name:
-        return "dconv"
+    m = re.search(r"dconv_kernel<\d+, \d+, (true|false)>", name)
+    if m:
+        return "dconv<epi=1>" if m.group(1) == "true" else "dconv"      # the RMSNorm-epilogue form is a class of its own
     m = re.search(r"tattn_wide_kernel<\d+, \w+, (\d)>", name)
     if m:
         return ("tattn_fused", "sattn_fused", "sla_fused_wide")[int(m.group(1))]

@@ -150,7 +150,8 @@ class Plan:
         bn = 64 if a.tile_bn == 64 else tile_for(a.epilogue, a.n)[0]
         in_rows = a.frames * a.main.in_h * a.main.in_w
         kernel = ("wsconv64" if lib.vdmi_wsconv_covers(C.byref(a)) else
-                  "dconv" if lib.vdmi_dconv_covers(C.byref(a)) else f"tapgemm<epi={a.epilogue},bn={bn}>")
+                  ("dconv" if a.epilogue == EPI_PLAIN else f"dconv<epi={a.epilogue}>") if lib.vdmi_dconv_covers(C.byref(a))
+                  else f"tapgemm<epi={a.epilogue},bn={bn}>")      # one class per kernel instantiation family
         meta = {"kernel": kernel, "flops": 2.0 * m * a.n * k,
                 "bytes": 2.0 * (in_rows * (a.main.c0 + a.main.c1) / (4 if a.main.space_to_depth else 1)
                                 + m * a.n + a.n * k)}
