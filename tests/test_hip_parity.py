@@ -1091,6 +1091,8 @@ def test_errors_are_loud():
     (16, 16, 5, 128, 64, 256, 2),      # one frame per tile, two sources of different widths
     (16, 32, 3, 64, 0, 128, 1),        # bands of a taller image: halo rows from the neighbouring band
     (32, 32, 2, 128, 0, 128, 2),       # 8-row bands of a 32-pixel-wide image
+    (64, 64, 2, 128, 0, 256, 1),       # 4-row bands of a 64-pixel-wide image
+    (64, 12, 3, 64, 64, 128, 2),       # the same, three bands per frame, two sources
 ])
 def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, ksplit):
     """The streaming (1,3,3) convolution of the wide layers (Block.proj, reference vdp.py:412-420) against the general
@@ -1145,6 +1147,7 @@ def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, kspli
     (16, 16, 6, 3, 64, 64, False, True),      # two sources, per-sample scale / shift (block1)
     (8, 8, 10, 5, 256, 0, True, False),       # four stacked frames per tile spanning two samples
     (32, 32, 2, 2, 64, 0, False, False),      # a single input chunk
+    (64, 64, 2, 1, 128, 0, True, True),       # 4-row bands of a 64-pixel-wide image
 ])
 def test_streaming_conv_with_norm_epilogue_matches_tapgemm_and_torch(W, H, frames, fpb, c0, c1, with_res, with_shift):
     """The streaming conv with the Block epilogue (conv + bias, RMSNorm over the 128 output channels, * gain + shift,

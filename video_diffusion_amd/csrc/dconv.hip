@@ -401,7 +401,7 @@ bool dc_covers(const vdmi_tapgemm_args& A) {
         // measured per launch of 8 samples: 32-pixel-wide images 42-45 -> 40-44 us, smaller images (80-tile launches)
         // 17-18 -> 18-19 us against the tap-GEMM's fused epilogue: only the former take this kernel.  (The choice
         // depends on the layer's shape alone, never on the batch.)
-        if (A.main.in_w != 32 && !g_dc_norm_all) return false;
+        if (A.main.in_w != 32 && A.main.in_w != 64 && !g_dc_norm_all) return false;
         if (A.has_res == 2 && (!A.res_identity || A.ld_res % 8 || !aligned16(A.res_identity))) return false;
         if (A.gain_bstride % 4 || A.shift_bstride % 4 || !aligned16(A.gain) || (A.shift && !aligned16(A.shift))) return false;
     } else if (A.epilogue != VDMI_EPI_PLAIN || A.act || A.has_res || A.n % 128 || A.tile_bn != 64) {
@@ -414,7 +414,7 @@ bool dc_covers(const vdmi_tapgemm_args& A) {
     if (A.out_mul > 1 || A.out_off_y || A.out_off_x) return false;
     const int H = m.in_h, W = m.in_w;
     if (A.grid_h != H || A.grid_w != W || A.out_h != H || A.out_w != W) return false;
-    if (!((W == 8 && H == 8) || (W == 16 && H % 16 == 0) || (W == 32 && H % 8 == 0))) return false;
+    if (!((W == 8 && H == 8) || (W == 16 && H % 16 == 0) || (W == 32 && H % 8 == 0) || (W == 64 && H % 4 == 0))) return false;
     const long long rows = (long long)A.frames * H * W;
     const int cmax = m.c0 > m.c1 ? m.c0 : m.c1;
     if (rows * cmax * 2 >= 0x7fffffffLL || rows * 8 >= 0x7fffffffLL) return false;
@@ -455,7 +455,7 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     k.H = H;
     k.frames = A.frames;
     k.rows = (long long)A.frames * H * W;
-    const int R = W == 8 ? 8 : (W == 16 ? 16 : 8);
+    const int R = W == 8 ? 8 : (W == 16 ? 16 : (W == 32 ? 8 : 4));
     k.bands = H / R;
     k.npx = W == 8 ? (A.frames + 3) / 4 : A.frames * k.bands;
     k.nnt = A.n / 128;
@@ -479,7 +479,7 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     const long long nwg = (long long)k.npx * k.nnt * k.ksplit;
     if (nwg > 0x7fffffffLL) return VDMI_E_SHAPE;
 
-    static std::atomic<uint64_t> attr_mask[6];
+    static std::atomic<uint64_t> attr_mask[8];
     const int PW = W + 2, PR = R + 2, NF = 256 / (R * W);
     const int npiece = (NF * PR * PW + 7) / 8;
     const size_t lds = (size_t)2 * npiece * 1024 + 3 * 16384;
@@ -493,7 +493,8 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     }
     if (W == 8) { if (norm) VDMI_DC_CASE(8, 8, true, 0) else VDMI_DC_CASE(8, 8, false, 1) }
     else if (W == 16) { if (norm) VDMI_DC_CASE(16, 16, true, 2) else VDMI_DC_CASE(16, 16, false, 3) }
-    else { if (norm) VDMI_DC_CASE(32, 8, true, 4) else VDMI_DC_CASE(32, 8, false, 5) }
+    else if (W == 32) { if (norm) VDMI_DC_CASE(32, 8, true, 4) else VDMI_DC_CASE(32, 8, false, 5) }
+    else { if (norm) VDMI_DC_CASE(64, 4, true, 6) else VDMI_DC_CASE(64, 4, false, 7) }
 #undef VDMI_DC_CASE
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
