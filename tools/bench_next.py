@@ -185,14 +185,20 @@ def guidance_step(args, dev):
     from video_diffusion_amd import VAE, train_hip, version1 as V1
     torch.manual_seed(0)
     B, F, S, ov = args.guid_batch, args.frames, args.guid_latent, 2
-    unet = V1.Unet3D(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
+    if args.guid_variant:
+        # the video_diffusion_guidance.py denoiser (TemporalSpatialBlocks, GroupNorm, per-frame spatial attention)
+        from video_diffusion_amd import guidance_variant as GV, train_hip_variant
+        train_hip = train_hip_variant           # its own shape test decides between the HIP layers and torch ops
+        unet = GV.Unet3D(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
+    else:
+        unet = V1.Unet3D(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
     vae = VAE(channels=3, latent_dim=4, base_dim=64)
     gd = V1.GaussianDiffusion(unet.eval(), vae.eval(), image_size=8 * S, num_frames=F, channels=3, timesteps=1000).to(dev)
     z = torch.randn(B, 4, F, S, S, device=dev)
     t = torch.full((B,), 500, device=dev, dtype=torch.long)
     prev = torch.rand(B, 3, ov, 8 * S, 8 * S, device=dev)
     fn = V1.temporal_consistency_guidance(gd, prev, ov, w_r=1.0)
-    out = {"workload": f"guided sampling step: version1.Unet3D(dim=64, channels=4) on latents {tuple(z.shape)}, reconstruction "
+    out = {"workload": f"guided sampling step: {'guidance_variant' if args.guid_variant else 'version1'}.Unet3D(dim=64, channels=4) on latents {tuple(z.shape)}, reconstruction "
                        f"guidance over {ov} overlap frames decoded to {8 * S}x{8 * S}, random-init weights",
            "supports_hip": bool(train_hip.supports(gd.denoise_fn)), "ms": {}}
     orig = train_hip.supports
@@ -212,6 +218,7 @@ def guidance_step(args, dev):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--guid-variant", action="store_true", help="time the video_diffusion_guidance.py denoiser instead of version1's")
     ap.add_argument("--guid-batch", type=int, default=2)
     ap.add_argument("--guid-latent", type=int, default=32)
     ap.add_argument("--train-batch", type=int, default=1)
