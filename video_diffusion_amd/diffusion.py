@@ -303,14 +303,15 @@ class GaussianDiffusion(nn.Module):
             plan.x_in.copy_(saved)
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
         plan.self_advancing = self_advancing
         plan.step_counter = tcount          # the captured kernel counts in it at every replay: it lives as long as the plan
         parts = getattr(plan, "parts", None)
         if self_advancing and self.pipeline_parts and isinstance(parts, list) and len(parts) > 1:
-            graph = self._staggered_steps(plan, rng, device)
+            graph = self._staggered_steps(plan, rng, device)        # one graph per part instead of the joined step
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
         runner = (graph, plan)
         self._graphs[key] = runner
         return runner
