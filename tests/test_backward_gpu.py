@@ -656,7 +656,8 @@ def _xattn_core_ref(q, kvrows, b, n, L, heads):
     return o, lse2
 
 
-@pytest.mark.parametrize("b,n,L,heads", [(1, 64, 32, 2), (2, 100, 37, 4), (1, 1000, 300, 8), (2, 515, 1024, 8), (1, 4096, 64, 1)])
+@pytest.mark.parametrize("b,n,L,heads", [(1, 64, 32, 2), (2, 100, 37, 4), (1, 1000, 300, 8), (2, 515, 1024, 8), (1, 4096, 64, 1),
+                                         (1, 5, 1, 1), (3, 33, 33, 2), (1, 20000, 257, 4)])      # one key; ragged by one; many chunks
 def test_cross_attention_core_forward_backward_vs_torch(b, n, L, heads):
     """vdmi_xattn_core_train_fwd / _bwd (CrossAttention.forward's softmax attention, vdp.py:511-521) against torch autograd
     over the same bf16 operands: output, log-sum-exp, and the gradients of q and of the projected key / value rows."""

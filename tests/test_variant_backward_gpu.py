@@ -20,7 +20,8 @@ def _bf(t):
 
 
 @pytest.mark.parametrize("c,b,rps,act,post,ld", [(64, 2, 1000, 1, True, 64), (128, 3, 515, 1, False, 128), (512, 1, 2048, 0, False, 512),
-                                                   (256, 2, 40000, 1, True, 320), (2048, 1, 70, 1, True, 2048)])
+                                                   (256, 2, 40000, 1, True, 320), (2048, 1, 70, 1, True, 2048),
+                                                   (64, 4, 1, 1, True, 64), (1024, 2, 3, 0, False, 1024)])      # one to three rows per sample
 def test_groupnorm_backward_vs_torch_autograd(c, b, rps, act, post, ld):
     """vdmi_groupnorm_bwd: dx and the per-(sample, channel) sums against autograd over F.group_norm -> SiLU -> affine."""
     from video_diffusion_amd import train_hip_variant as HV
