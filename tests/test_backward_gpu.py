@@ -796,3 +796,74 @@ def test_unet_backward_with_frame_conditioning_on_the_hip_kernels():
     assert record("unet_bwd_framecond.features_grad", rel_err(gf_hip, gf_ref), 6e-2) < 6e-2
     assert record("unet_bwd_framecond.cross_attn_param_grads", rel_err(xa(g_hip), xa(g_ref)), 6e-2) < 6e-2
     assert record("unet_bwd_framecond.all_param_grads", rel_err(cat(g_hip), cat(g_ref)), 6e-2) < 6e-2
+
+
+@pytest.mark.parametrize("c,f,h,w,heads", [(64, 3, 8, 8, 4), (128, 5, 10, 6, 8)])
+def test_spatio_temporal_attention_layer_forward_backward_vs_torch_autograd(c, f, h, w, heads):
+    """Residual(PreNorm(SpatioTemporalAttention)) of the version-1 variant (version1diffusion.py:325-345: every token
+    attends to all f*h*w tokens of its sample) on the cross-attention kernels, against the explicit softmax of autograd.py."""
+    from video_diffusion_amd import autograd as A, train_hip as T
+    from video_diffusion_amd.modules import PreNorm, Residual
+    from video_diffusion_amd.version1 import SpatioTemporalAttention
+    torch.manual_seed(4)
+    layer = Residual(PreNorm(c, SpatioTemporalAttention(c, heads=heads, dim_head=32))).to(DEV)
+    with torch.no_grad():
+        layer.fn.norm.gamma.copy_(1 + 0.2 * torch.randn_like(layer.fn.norm.gamma))
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, c, f, h, w, generator=g).to(DEV)
+    dout = torch.randn(2, c, f, h, w, generator=g).to(DEV)
+
+    def run(fn):
+        xr = x.clone().requires_grad_(True)
+        for p in layer.parameters():
+            p.grad = None
+        out = fn(layer, xr)
+        out.backward(dout)
+        grads = {n: p.grad.clone() for n, p in layer.named_parameters()}
+        grads["x"] = xr.grad.clone()
+        return out.detach().float(), grads
+
+    out_ref, g_ref = run(A._linear_attention_ops)
+    out_hip, g_hip = run(T.spatio_temporal_attention)
+    tag = f"st_attn_layer.c{c}"
+    assert record(tag + ".out", rel_err(out_hip, out_ref), 1e-2) < 1e-2
+    assert set(g_hip) == set(g_ref)
+    for name in sorted(g_ref):
+        assert g_hip[name].shape == g_ref[name].shape, name
+        assert record(f"{tag}.grad.{name}", rel_err(g_hip[name], g_ref[name]), 3e-2) < 3e-2, name
+
+
+@pytest.mark.parametrize("cin,cout,temb", [(64, 128, 32), (64, 64, None)])
+def test_version1_resnet_block_with_temporal_conv_vs_torch_autograd(cin, cout, temb):
+    """The version-1 ResnetBlock (version1diffusion.py:301-323: the packaged block, then a (3,1,1) convolution over frames,
+    then the residual branch) entirely on the library: output and every gradient against the torch ops of autograd.py."""
+    from video_diffusion_amd import autograd as A, train_hip as T
+    rb = _rand_block(cin, cout, temb, 13)
+    rb.temporal_conv = torch.nn.Conv3d(cout, cout, (3, 1, 1), padding=(1, 0, 0)).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    b, f, h, w = 2, 4, 8, 8
+    x = torch.randn(b, cin, f, h, w, generator=g).to(DEV)
+    te = torch.randn(b, temb, generator=g).to(DEV) if temb else None
+    dout = torch.randn(b, cout, f, h, w, generator=g).to(DEV)
+    seen = []
+    orig = T.TemporalConvResFn.apply
+
+    def run(fn):
+        xr = x.clone().requires_grad_(True)
+        ter = te.clone().requires_grad_(True) if te is not None else None
+        for p in rb.parameters():
+            p.grad = None
+        out = fn(rb, xr, ter)
+        out.backward(dout)
+        grads = {n: p.grad.clone() for n, p in rb.named_parameters()}
+        grads["x"] = xr.grad.clone()
+        return out.detach().float(), grads
+
+    out_ref, g_ref = run(A._resnet)
+    out_hip, g_hip = run(T.resnet_block)
+    tag = f"v1_resnet_bwd.{cin}to{cout}"
+    assert record(tag + ".out", rel_err(out_hip, out_ref), 2e-2) < 2e-2
+    assert set(g_hip) == set(g_ref) and "temporal_conv.weight" in g_hip
+    for name in sorted(g_ref):
+        assert g_hip[name].shape == g_ref[name].shape, name
+        assert record(f"{tag}.grad.{name}", rel_err(g_hip[name], g_ref[name]), 3e-2) < 3e-2, name

@@ -184,6 +184,10 @@ def _linear_attention(res, x):
     if _HIP_ATTN and x.is_cuda and isinstance(sl.to_qkv, torch.nn.Conv2d):
         from .train_hip import spatial_linear_attention     # forward and backward on the HIP kernels
         return spatial_linear_attention(res, x)
+    if (_HIP_ATTN and x.is_cuda and isinstance(sl.to_qkv, torch.nn.Linear) and getattr(sl, "dim_head", 32) == 32
+            and sl.to_qkv.bias is None and sl.to_out.bias is None):
+        from .train_hip import spatio_temporal_attention    # SpatioTemporalAttention: the cross-attention kernels, context = x
+        return spatio_temporal_attention(res, x)
     return _torch_ops(lambda x: _linear_attention_ops(res, x), x)
 
 

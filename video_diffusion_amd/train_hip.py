@@ -158,6 +158,46 @@ def conv_rows(src: torch.Tensor, pack: DevPack, bias, frames: int, fpb: int, h: 
     return out
 
 
+def frame_conv_rows(src, pack: "DevPack", bias, b, f, hw, residual=None):
+    """Conv3d(cin, n, (k,1,1), padding (k/2,0,0)) over rows (+ bias, + residual rows): each sample is an f x hw 'image'
+    whose k taps step along its first axis."""
+    k = pack.ntaps
+    out = torch.empty(b * f * hw, pack.n, device=src.device, dtype=torch.bfloat16)
+    a = TapGemmArgs()
+    a.frames, a.frames_per_batch = b, 1
+    a.grid_h, a.grid_w, a.out_h, a.out_w = f, hw, f, hw
+    a.out_mul = 1
+    a.out, a.ldo, a.n, a.epilogue = out.data_ptr(), pack.n, pack.n, EPI_PLAIN
+    p = a.main
+    p.src0, p.c0, p.c1 = src.data_ptr(), pack.k, 0
+    p.in_h, p.in_w, p.stride, p.ntaps = f, hw, 1, k
+    for i in range(k):
+        p.dy[i], p.dx[i] = i - k // 2, 0
+    p.w = pack.data.data_ptr()
+    a.bias = None if bias is None else bias.data_ptr()
+    a.tile_bn = pack.tile_bn
+    if residual is not None:
+        a.has_res, a.res_identity, a.ld_res = 2, residual.data_ptr(), residual.shape[1]
+    check(_lib.lib().vdmi_tapgemm(C.byref(a), _stream()), "vdmi_tapgemm")
+    return out
+
+
+def frame_conv_wgrad(xr, dy, b, f, hw, k):
+    """float32 (cout, cin, k, 1, 1) weight gradient of that convolution: tap j pairs dy[b, f'] with x[b, f' + j - k/2], so
+    each tap is a row GEMM over a frame-shifted, zero-filled copy of x."""
+    c, cout = xr.shape[1], dy.shape[1]
+    x5 = xr.view(b, f, hw, c)
+    taps = []
+    for j in range(k):
+        s = j - k // 2
+        xs = torch.zeros_like(x5)
+        lo, hi = max(0, -s), min(f, f - s)
+        if hi > lo:
+            xs[:, lo:hi] = x5[:, lo + s:hi + s]
+        taps.append(rows_wgrad(xs.view(-1, c), dy))
+    return torch.stack(taps, dim=-1).reshape(cout, c, k, 1, 1)
+
+
 def rmsnorm_silu_rows(y, gain, shift, bstride, rows_per_batch, residual=None):
     rows, c = y.shape
     out = torch.empty_like(y)
@@ -407,6 +447,47 @@ def pointwise_conv(conv: torch.nn.Conv3d, x: torch.Tensor) -> torch.Tensor:
     return PointwiseConvFn.apply(x, conv.weight, conv.bias)
 
 
+class TemporalConvResFn(torch.autograd.Function):
+    """The tail of the version-1 ResnetBlock (version1diffusion.py:308, 320-323): temporal_conv(h) + res_conv(x), a
+    (k,1,1) convolution over frames plus the block's residual branch (1x1 convolution or identity)."""
+
+    @staticmethod
+    @_plain
+    def forward(ctx, h, x, wt, bt, wres, bres):
+        b, c, f, hh, ww = h.shape
+        hw = hh * ww
+        hr, xr = to_rows(h), to_rows(x)
+        fz = lambda t: None if t is None else t.detach().float().contiguous()
+        r = xr if wres is None else conv_rows(xr, param_pack(wres, False), fz(bres), b * f, f, hh, ww)
+        out = frame_conv_rows(hr, param_pack(wt, False), fz(bt), b, f, hw, residual=r)
+        ctx.save_for_backward(hr, xr, wt, wres)
+        ctx.meta = (b, c, x.shape[1], f, hh, ww, wt.shape[2])
+        ctx.acts = (_act_dtype(h), _act_dtype(x))
+        return from_rows(out, b, f, hh, ww, ctx.acts[0])
+
+    @staticmethod
+    @_plain
+    def backward(ctx, dout):
+        hr, xr, wt, wres = ctx.saved_tensors
+        b, c, cin, f, hh, ww, k = ctx.meta
+        need = ctx.needs_input_grad
+        hw, frames = hh * ww, b * f
+        do = to_rows(dout)
+        dh = from_rows(frame_conv_rows(do, param_pack(wt, True), None, b, f, hw), b, f, hh, ww, ctx.acts[0]) if need[0] else None
+        dwt = frame_conv_wgrad(hr, do, b, f, hw, k) if need[2] else None
+        dbt = colsum_rows(do) if need[3] else None
+        dwres = dbres = None
+        if wres is None:
+            dx = from_rows(do, b, f, hh, ww, ctx.acts[1]) if need[1] else None
+        else:
+            dx = from_rows(conv_rows(do, param_pack(wres, True), None, frames, f, hh, ww), b, f, hh, ww, ctx.acts[1]) if need[1] else None
+            if need[4]:
+                dwres = rows_wgrad(xr, do).view(c, cin, 1, 1, 1)
+            if need[5]:
+                dbres = colsum_rows(do)
+        return dh, dx, dwt, dbt, dwres, dbres
+
+
 def resnet_block(rb, x: torch.Tensor, temb) -> torch.Tensor:
     """autograd.py's `_resnet` on the HIP kernels.  The variant's block (version1diffusion.py:308, 320-323: a (3,1,1)
     convolution over frames between block2 and the residual) runs its two Blocks here and the rest as torch ops."""
@@ -420,7 +501,10 @@ def resnet_block(rb, x: torch.Tensor, temb) -> torch.Tensor:
             rb.block2.proj.weight, rb.block2.proj.bias, rb.block2.norm.gamma)
     tconv = getattr(rb, "temporal_conv", None)
     if tconv is not None:
-        return torch_ops(lambda y, xin: tconv(y) + rc(xin), ResnetBlockFn.apply(*args, None, None, False), x)
+        h = ResnetBlockFn.apply(*args, None, None, False)
+        if tconv.kernel_size[1:] == (1, 1) and tconv.kernel_size[0] % 2 == 1 and tconv.padding == (tconv.kernel_size[0] // 2, 0, 0):
+            return TemporalConvResFn.apply(h, x, tconv.weight, tconv.bias, wres, bres)
+        return torch_ops(lambda y, xin: tconv(y) + rc(xin), h, x)
     return ResnetBlockFn.apply(*args, wres, bres)
 
 
@@ -626,6 +710,88 @@ class CrossAttnFn(torch.autograd.Function):
             dwkv = rows_wgrad(crow, dkv)
             dwk, dwv = dwkv[:hid].contiguous(), dwkv[hid:].contiguous()
         return from_rows(dx, b, f, h, w, ctx.act), dctx, dgamma, dwq, dwk, dwv, dwout, dbout, None, None, None
+
+
+class SelfAttnFn(torch.autograd.Function):
+    """Residual(PreNorm(SpatioTemporalAttention)) of the version-1 variant (version1diffusion.py:325-345): softmax attention
+    of every token of a sample to all f*h*w tokens of that sample, no bias, no rotary - the cross-attention kernels with
+    the sample's own normalised rows as the context.  gamma (1, C, 1, 1, 1); wqkv (3*heads*32, C); wout (C, heads*32)."""
+
+    @staticmethod
+    @_plain
+    def forward(ctx, x, gamma, wqkv, wout, heads, scale, eps):
+        if not x.is_cuda:
+            raise _lib.VdmiError("the HIP training backend needs CUDA (HIP) tensors; there is no CPU path")
+        lib = _lib.lib()
+        b, c, f, h, w = x.shape
+        n, hid = f * h * w, heads * 32
+        rows = b * n
+        assert wqkv.shape == (3 * hid, c) and wout.shape == (c, hid)
+        xr = to_rows(x)
+        xh = torch.empty_like(xr)
+        check(lib.vdmi_layernorm_rows(xr.data_ptr(), xh.data_ptr(), rows, c, eps, _stream()), "vdmi_layernorm_rows")
+        cs = scale * _LOG2E
+        fold = torch.ones(3 * hid, 1, device=x.device)
+        fold[:hid] = cs                                    # q rows also carry the softmax scale and log2 e
+        w_eff = (wqkv.detach() * gamma.detach().reshape(1, c) * fold).contiguous()
+        qkv = conv_rows(xh, _linear_pack(w_eff, False), None, b * f, f, h, w)        # [rows][q | k | v]
+        kv_ptr = qkv.data_ptr() + hid * 2                                            # k, v columns: row stride 3 * hid
+        pack = torch.empty(2 * lib.vdmi_xattn_kv_elems(1, b, n, heads), device=x.device, dtype=torch.bfloat16)
+        check(lib.vdmi_xattn_pack_kv_train(kv_ptr, 3 * hid, pack.data_ptr(), b, n, heads, _stream()), "vdmi_xattn_pack_kv_train")
+        npad = (n + 31) // 32 * 32
+        o = torch.empty(rows, hid, device=x.device, dtype=torch.bfloat16)
+        lse = torch.zeros(b, heads, npad, device=x.device, dtype=torch.float32)
+        check(lib.vdmi_xattn_core_train_fwd(qkv.data_ptr(), 3 * hid, o.data_ptr(), pack.data_ptr(), lse.data_ptr(), npad, b, n, n,
+                                            heads, _stream()), "vdmi_xattn_core_train_fwd")
+        perm = _stored_feature_order(hid, x.device)
+        wout_p = wout.detach()[:, perm].contiguous()
+        y = conv_rows(o, _linear_pack(wout_p, False), None, b * f, f, h, w, residual=xr)
+        ctx.save_for_backward(xr, xh, qkv, pack, o, lse, w_eff, wout_p, perm, wqkv, gamma, fold)
+        ctx.meta = (b, c, f, h, w, heads, eps, npad)
+        ctx.act = _act_dtype(x)
+        return from_rows(y, b, f, h, w, ctx.act)
+
+    @staticmethod
+    @_plain
+    def backward(ctx, dy):
+        xr, xh, qkv, pack, o, lse, w_eff, wout_p, perm, wqkv, gamma, fold = ctx.saved_tensors
+        b, c, f, h, w, heads, eps, npad = ctx.meta
+        lib = _lib.lib()
+        n, hid, frames = f * h * w, heads * 32, b * f
+        rows = b * n
+        need = ctx.needs_input_grad
+        dyr = to_rows(dy)
+        do = conv_rows(dyr, _linear_pack(wout_p, True), None, frames, f, h, w)
+        dwout = None
+        if need[3]:
+            dwout = torch.empty(c, hid, device=dy.device, dtype=torch.float32)
+            dwout[:, perm] = rows_wgrad(o, dyr)
+        dq = torch.empty(rows, hid, device=dy.device, dtype=torch.bfloat16)
+        dkv = torch.empty(rows, 2 * hid, device=dy.device, dtype=torch.bfloat16)
+        delta = torch.zeros(b, heads, npad, device=dy.device, dtype=torch.float32)
+        ws = torch.empty(lib.vdmi_xattn_bwd_workspace_bytes(b, n, n, heads), device=dy.device, dtype=torch.uint8)
+        check(lib.vdmi_xattn_core_train_bwd(qkv.data_ptr(), 3 * hid, o.data_ptr(), do.data_ptr(), pack.data_ptr(),
+                                            qkv.data_ptr() + hid * 2, 3 * hid, lse.data_ptr(), delta.data_ptr(), npad,
+                                            dq.data_ptr(), dkv.data_ptr(), 2 * hid, b, n, n, heads, ws.data_ptr(), _stream()),
+              "vdmi_xattn_core_train_bwd")
+        dqkv = torch.cat((dq, dkv), dim=1)
+        dxh = conv_rows(dqkv, _linear_pack(w_eff, True), None, frames, f, h, w)
+        dwqkv = dgamma = None
+        if need[1] or need[2]:
+            dwe = rows_wgrad(xh, dqkv)
+            dwqkv = dwe * gamma.detach().reshape(1, c) * fold
+            dgamma = (dwe * wqkv.detach() * fold).sum(0).reshape(gamma.shape)
+        dx = torch.empty_like(xr)
+        check(lib.vdmi_layernorm_rows_bwd(xr.data_ptr(), dxh.data_ptr(), dyr.data_ptr(), dx.data_ptr(), rows, c, eps,
+                                          _stream()), "vdmi_layernorm_rows_bwd")
+        return from_rows(dx, b, f, h, w, ctx.act), dgamma, dwqkv, dwout, None, None, None
+
+
+def spatio_temporal_attention(res, x: torch.Tensor) -> torch.Tensor:
+    """autograd.py's `_linear_attention` (the SpatioTemporalAttention form of the version-1 variant) on the HIP kernels."""
+    att = res.fn.fn
+    return SelfAttnFn.apply(x, res.fn.norm.gamma, att.to_qkv.weight, att.to_out.weight, att.heads, float(att.scale),
+                            float(res.fn.norm.eps))
 
 
 def cross_attention_fits(ca, context) -> bool:

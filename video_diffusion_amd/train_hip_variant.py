@@ -22,9 +22,9 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import EPI_PLAIN, TapGemmArgs, check
-from .train_hip import (DevPack, TemporalAttnFn, _act_dtype, _plain, _stream, attention_core_fits, colsum_rows, conv_rows,
-                        conv_wgrad, from_rows, param_pack, rows_transposed, rows_wgrad, to_rows, torch_ops)
+from ._lib import check
+from .train_hip import (TemporalAttnFn, _act_dtype, _plain, _stream, attention_core_fits, colsum_rows, conv_rows, conv_wgrad,
+                        frame_conv_rows, frame_conv_wgrad, from_rows, param_pack, rows_transposed, rows_wgrad, to_rows, torch_ops)
 
 
 def _f(t):
@@ -77,28 +77,6 @@ def dwconv_wgrad_rows(x, du, b, f, hw, k):
     check(lib.vdmi_temporal_dwconv_wgrad(x.data_ptr(), du.data_ptr(), part.data_ptr(), C.byref(ns), b, f, hw, c, k, _stream()),
           "vdmi_temporal_dwconv_wgrad")
     return part.view(ns.value, c, k + 1).sum(0)
-
-
-def frame_conv_rows(src, pack: DevPack, bias, b, f, hw):
-    """Conv3d(cin, n, (k,1,1), padding (k/2,0,0)) over rows: each sample is an f x hw 'image' whose k taps step along its
-    first axis."""
-    k = pack.ntaps
-    out = torch.empty(b * f * hw, pack.n, device=src.device, dtype=torch.bfloat16)
-    a = TapGemmArgs()
-    a.frames, a.frames_per_batch = b, 1
-    a.grid_h, a.grid_w, a.out_h, a.out_w = f, hw, f, hw
-    a.out_mul = 1
-    a.out, a.ldo, a.n, a.epilogue = out.data_ptr(), pack.n, pack.n, EPI_PLAIN
-    p = a.main
-    p.src0, p.c0, p.c1 = src.data_ptr(), pack.k, 0
-    p.in_h, p.in_w, p.stride, p.ntaps = f, hw, 1, k
-    for i in range(k):
-        p.dy[i], p.dx[i] = i - k // 2, 0
-    p.w = pack.data.data_ptr()
-    a.bias = None if bias is None else bias.data_ptr()
-    a.tile_bn = pack.tile_bn
-    check(_lib.lib().vdmi_tapgemm(C.byref(a), _stream()), "vdmi_tapgemm")
-    return out
 
 
 class TemporalSpatialFn(torch.autograd.Function):
@@ -189,17 +167,7 @@ class FrameConvNormFn(torch.autograd.Function):
         dy, chan = groupnorm_bwd_rows(y, to_rows(dout), groups, gv, bev, eps, b, 0)
         dwc = dbc = dg = dbe = None
         if need[1]:
-            # tap j pairs dy[b, f'] with x[b, f' + j - k/2]: a shifted (zero-filled) copy of x per tap, then a rows GEMM
-            x5 = xr.view(b, f, hw, c)
-            taps = []
-            for j in range(k):
-                s = j - k // 2
-                xs = torch.zeros_like(x5)
-                lo, hi = max(0, -s), min(f, f - s)
-                if hi > lo:
-                    xs[:, lo:hi] = x5[:, lo + s:hi + s]
-                taps.append(rows_wgrad(xs.view(-1, c), dy))
-            dwc = torch.stack(taps, dim=-1).reshape(cout, c, k, 1, 1)
+            dwc = frame_conv_wgrad(xr, dy, b, f, hw, k)
         if need[2] or need[3] or need[4]:
             tot = chan.sum(0)
             dbe, dg = tot[:, 0].contiguous(), tot[:, 1].contiguous()
