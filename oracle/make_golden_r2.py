@@ -1,4 +1,4 @@
-"""Round-2 fixtures from the REAL reference (build container only; TEST INFRASTRUCTURE).
+"""Full-loop and full-size fixtures from the REAL reference (build container only; TEST INFRASTRUCTURE).
 
     python -m oracle.make_golden_r2            # from the repo root
 
