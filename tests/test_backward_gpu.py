@@ -867,3 +867,35 @@ def test_version1_resnet_block_with_temporal_conv_vs_torch_autograd(cin, cout, t
     for name in sorted(g_ref):
         assert g_hip[name].shape == g_ref[name].shape, name
         assert record(f"{tag}.grad.{name}", rel_err(g_hip[name], g_ref[name]), 3e-2) < 3e-2, name
+
+
+def test_hip_backend_under_autocast_with_focus_flags_and_frame_conditioning():
+    """Trainer(amp=True) wraps the loss in torch.autocast: the HIP layers ignore it (their Functions run outside autocast
+    on bf16 rows), the few torch layers left (embeddings) follow it.  A step with focus-present flags (vdp.py:590-600) and
+    previous-frame features (vdp.py:803-805) under bf16 autocast: loss and gradients against the all-torch backend under
+    the same autocast, which normalises in float."""
+    from tests.helpers import inp, make_unet
+    m = make_unet(salt=5, dim=64, dim_mults=(1, 2), channels=3).to(DEV)
+    x = inp("amp.x", (2, 3, 4, 16, 16)).to(DEV)
+    noise = inp("amp.noise", (2, 3, 4, 16, 16)).to(DEV)
+    feats = inp("amp.feat", (2, 24, 512)).to(DEV)
+    t = torch.tensor([400, 30], device=DEV)
+    focus = torch.tensor([False, True], device=DEV)
+
+    def run(backend):
+        m.train_backend = backend
+        for p in m.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(x, t, frame_cond_features=feats, focus_present_mask=focus)
+            loss = F.mse_loss(out.float(), noise)
+        loss.backward()
+        m.train_backend = None
+        return loss.detach(), {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    l_ref, g_ref = run("torch-autograd")
+    l_hip, g_hip = run("hip")
+    assert set(g_ref) == set(g_hip)
+    cat = lambda d: torch.cat([d[n].flatten() for n in sorted(d)])
+    assert record("amp_focus_framecond.loss", abs(float(l_hip - l_ref)) / float(l_ref), 2e-2) < 2e-2
+    assert record("amp_focus_framecond.all_param_grads", rel_err(cat(g_hip), cat(g_ref)), 4e-2) < 4e-2
