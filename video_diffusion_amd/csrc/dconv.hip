@@ -261,8 +261,10 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
             kstep(0, wb, pb, ab, xv, 1);
             kstep(1, wb, pb, ab, xv, 2);
             // the only request younger than tile s + 1 is the patch piece of the step before (steps 1 .. NU)
+#ifndef VDMI_DC_ABL_NOWAIT      // timing-only ablation build (wrong results): how much of a step is waiting for the weight tile
             if (t >= 1 && t <= NU) wait_vm<1>();
             else wait_vm<0>();
+#endif
             __builtin_amdgcn_s_barrier();
             issue_weights(s + 2, slot2);
             if (t < NU) issue_patch_piece(buf ^ 1, t);
