@@ -265,7 +265,9 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
             if (t >= 1 && t <= NU) wait_vm<1>();
             else wait_vm<0>();
 #endif
+#ifndef VDMI_DC_ABL_NOBARRIER   // second timing-only ablation: the cost of the mid-step barrier
             __builtin_amdgcn_s_barrier();
+#endif
             issue_weights(s + 2, slot2);
             if (t < NU) issue_patch_piece(buf ^ 1, t);
             kstep(0, wb, pb, ab, xv, 3);
