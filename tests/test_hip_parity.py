@@ -1142,14 +1142,18 @@ def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, kspli
     assert (y_new != y_old).float().mean() < 0.05
 
 
-@pytest.mark.parametrize("W,H,frames,fpb,c0,c1,with_res,with_shift", [
-    (32, 32, 4, 2, 128, 0, True, True),       # 8-row bands, identity residual (block2 of a ResnetBlock)
-    (16, 16, 6, 3, 64, 64, False, True),      # two sources, per-sample scale / shift (block1)
-    (8, 8, 10, 5, 256, 0, True, False),       # four stacked frames per tile spanning two samples
-    (32, 32, 2, 2, 64, 0, False, False),      # a single input chunk
-    (64, 64, 2, 1, 128, 0, True, True),       # 4-row bands of a 64-pixel-wide image
+@pytest.mark.parametrize("W,H,frames,fpb,c0,c1,with_res,with_shift,n", [
+    (32, 32, 4, 2, 128, 0, True, True, 128),       # 8-row bands, identity residual (block2 of a ResnetBlock)
+    (16, 16, 6, 3, 64, 64, False, True, 128),      # two sources, per-sample scale / shift (block1)
+    (8, 8, 10, 5, 256, 0, True, False, 128),       # four stacked frames per tile spanning two samples
+    (32, 32, 2, 2, 64, 0, False, False, 128),      # a single input chunk
+    (64, 64, 2, 1, 128, 0, True, True, 128),       # 4-row bands of a 64-pixel-wide image
+    (64, 64, 4, 2, 64, 64, False, True, 64),       # 64 output channels: the contraction split over the wave groups
+    (32, 32, 6, 3, 128, 128, False, True, 64),     # the same on a 32-pixel-wide image, four input chunks
+    (64, 8, 3, 1, 128, 0, True, False, 64),        # with an identity residual, two bands per frame
+    (8, 8, 10, 5, 64, 64, False, True, 64),        # stacked frames (only reachable with every width enabled)
 ])
-def test_streaming_conv_with_norm_epilogue_matches_tapgemm_and_torch(W, H, frames, fpb, c0, c1, with_res, with_shift):
+def test_streaming_conv_with_norm_epilogue_matches_tapgemm_and_torch(W, H, frames, fpb, c0, c1, with_res, with_shift, n):
     """The streaming conv with the Block epilogue (conv + bias, RMSNorm over the 128 output channels, * gain + shift,
     SiLU, + identity residual: reference vdp.py:391-427, 452) against the tap-GEMM's fused epilogue on the same
     arguments and against torch ops on the bf16-rounded operands."""
@@ -1157,16 +1161,16 @@ def test_streaming_conv_with_norm_epilogue_matches_tapgemm_and_torch(W, H, frame
     from video_diffusion_amd import _lib
     from video_diffusion_amd.engine import PackedTaps, TAPS_3x3, _fill_pass
     lib = _lib.lib()
-    n, cin, nb = 128, c0 + c1, frames // fpb
+    cin, nb = c0 + c1, frames // fpb
     rows = frames * H * W
-    wt = inp(f"dconvn.w{W}.{cin}", (n, cin, 9), scale=(9 * cin) ** -0.5)
-    bias = inp("dconvn.b", (n,), scale=0.1).to(dev())
-    gain = (1.0 + 0.5 * inp(f"dconvn.g{nb}", (nb, n))).contiguous().to(dev())
-    shift = inp(f"dconvn.s{nb}", (nb, n)).contiguous().to(dev()) if with_shift else None
+    wt = inp(f"dconvn.w{W}.{cin}.{n}", (n, cin, 9), scale=(9 * cin) ** -0.5)
+    bias = inp(f"dconvn.b{n}", (n,), scale=0.1).to(dev())
+    gain = (1.0 + 0.5 * inp(f"dconvn.g{nb}.{n}", (nb, n))).contiguous().to(dev())
+    shift = inp(f"dconvn.s{nb}.{n}", (nb, n)).contiguous().to(dev()) if with_shift else None
     pk = PackedTaps(wt, c0, c1, _lib.EPI_NORM_SILU, dev())
     x0 = inp(f"dconvn.x0.{W}.{c0}", (rows, c0)).to(ACT).to(dev())
     x1 = inp(f"dconvn.x1.{W}.{c1}", (rows, c1)).to(ACT).to(dev()) if c1 else None
-    res = inp(f"dconvn.r{W}", (rows, n)).to(ACT).to(dev()) if with_res else None
+    res = inp(f"dconvn.r{W}.{n}", (rows, n)).to(ACT).to(dev()) if with_res else None
 
     def run(enable):
         out = torch.full((rows, n), float("nan"), device=dev(), dtype=ACT)

@@ -79,12 +79,18 @@ __device__ __forceinline__ void wait_vm() {
 // the tile stacks NF = 256 / (R * W) sub-blocks.
 // NORM: bias, RMSNorm over the 128 output channels, * gain + shift, SiLU, + identity residual (Block.forward and the
 // ResnetBlock sum, reference vdp.py:391-427, 452) instead of the plain epilogue.
-template <int W, int R, bool NORM>
+// N64: the layer has 64 output channels (the 128 -> 64 Blocks of the full-resolution levels).  The tile is 256 pixels x
+// 64 channels and the two wave groups split the CONTRACTION instead of the channels: wave group wk takes k-steps 2 wk and
+// 2 wk + 1 of every (chunk, tap) step over all 64 channels (the same 64 x 64 block per wave, 8 MFMAs per wave and step),
+// weight tiles are 8 KiB, and the two partial blocks of a pixel group are added through LDS before the epilogue, which
+// each wave then runs for 32 of the 64 pixels with all of their channels in its own registers.  NORM only.
+template <int W, int R, bool NORM, bool N64 = false>
 __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
+    static_assert(!N64 || NORM, "the 64-channel form exists with the normalisation epilogue only");
     constexpr int NF = 256 / (R * W), PW = W + 2, PR = R + 2, NPP = NF * PR * PW;
     constexpr int NPIECE = (NPP + 7) / 8, PBUF = NPIECE * 1024, NU = (NPIECE + 7) / 8;
     constexpr int S = (W == 8) ? 4 : 0;
-    constexpr int WOFF = 2 * PBUF, WSLOT = 128 * 64 * 2, RING = 3;
+    constexpr int WOFF = 2 * PBUF, WSLOT = (N64 ? 64 : 128) * 64 * 2, RING = 3;
     static_assert(NF * R * W == 256 && NU <= 7, "tile geometry");
     static_assert(WOFF + RING * WSLOT <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,12 +155,13 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
     };
     // weight tile of step s = (chunk, tap): 16 KiB contiguous in the packed order; this wave's two 1-KiB pieces
     const unsigned wlane = (unsigned)(lane * 16 + wave * 1024);
-    const unsigned wbase0 = (unsigned)((c_begin * 9 * a.npad32 + nt * 4) * 4096), wstep = (unsigned)(a.npad32 * 4096);
+    const unsigned wbase0 = (unsigned)((c_begin * 9 * a.npad32 + nt * (N64 ? 2 : 4)) * 4096), wstep = (unsigned)(a.npad32 * 4096);
     auto issue_weights = [&](int s, int slot) {
         const unsigned off = s < nsteps ? wbase0 + (unsigned)s * wstep + wlane : 0x80000000u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(smem + WOFF + slot * WSLOT + wave * 1024), 16, off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(smem + WOFF + slot * WSLOT + 8192 + wave * 1024), 16,
-                                                 s < nsteps ? off + 8192u : 0x80000000u, 0, 0, 0);
+        if constexpr (!N64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(smem + WOFF + slot * WSLOT + 8192 + wave * 1024), 16,
+                                                     s < nsteps ? off + 8192u : 0x80000000u, 0, 0, 0);
     };
 
     // ---- patch addresses of this lane's pixel in each of the wave's two 32-pixel blocks
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
     // fragments (32 pixels each).  Two register sets alternate, so the reads of k-step k + 1 are in flight during the
     // products of k-step k; the order is pinned (left alone the compiler reads, waits and multiplies per k-step).
     bf16x8 fa[2][2], fb[2][2];
-    const char* wlds = smem + WOFF + wn * 8192 + lane * 16;
+    const char* wlds = smem + WOFF + (N64 ? 0 : wn * 8192) + lane * 16;
+    [[maybe_unused]] const int ka = 2 * wn, kb = 2 * wn + 1;        // N64: this wave group's two k-steps of every step
     auto tap_addr = [&](int t, int (&ab)[2], int (&xv)[2]) {
         const int dy = t / 3 - 1, dxi = t % 3;
 #pragma unroll
@@ -226,16 +234,17 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
     issue_weights(0, 0);
     issue_weights(1, 1);
     DC_STAMP(1);
-    wait_vm<2>();                       // patch and tile 0 (tile 1 may still be on its way)
+    wait_vm<(N64 ? 1 : 2)>();           // patch and tile 0 (tile 1 may still be on its way)
     __builtin_amdgcn_s_barrier();
     DC_STAMP(2);
     {
         int ab[2], xv[2];
         tap_addr(0, ab, xv);
-        fa[0][0] = *reinterpret_cast<const bf16x8*>(wlds);
-        fa[0][1] = *reinterpret_cast<const bf16x8*>(wlds + 4 * 1024);
-        fb[0][0] = *reinterpret_cast<const bf16x8*>(smem + ab[0] + xv[0]);
-        fb[0][1] = *reinterpret_cast<const bf16x8*>(smem + ab[1] + xv[1]);
+        const int k0 = N64 ? ka : 0;
+        fa[0][0] = *reinterpret_cast<const bf16x8*>(wlds + k0 * 1024);
+        fa[0][1] = *reinterpret_cast<const bf16x8*>(wlds + (4 + k0) * 1024);
+        fb[0][0] = *reinterpret_cast<const bf16x8*>(smem + ab[0] + ((k0 << 5) ^ xv[0]));
+        fb[0][1] = *reinterpret_cast<const bf16x8*>(smem + ab[1] + ((k0 << 5) ^ xv[1]));
     }
 
     // ---- main loop.  Step s = (chunk c, tap t):
@@ -258,8 +267,12 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
             if (slot1 == RING) slot1 = 0;
             int slot2 = slot1 + 1;
             if (slot2 == RING) slot2 = 0;
-            kstep(0, wb, pb, ab, xv, 1);
-            kstep(1, wb, pb, ab, xv, 2);
+            if constexpr (N64) {
+                kstep(0, wb, pb, ab, xv, kb);
+            } else {
+                kstep(0, wb, pb, ab, xv, 1);
+                kstep(1, wb, pb, ab, xv, 2);
+            }
             // the only request younger than tile s + 1 is the patch piece of the step before (steps 1 .. NU)
 #ifndef VDMI_DC_ABL_NOWAIT      // timing-only ablation build (wrong results): how much of a step is waiting for the weight tile
             if (t >= 1 && t <= NU) wait_vm<1>();
@@ -270,8 +283,12 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
 #endif
             issue_weights(s + 2, slot2);
             if (t < NU) issue_patch_piece(buf ^ 1, t);
-            kstep(0, wb, pb, ab, xv, 3);
-            kstep(1, wlds + slot1 * WSLOT, t == 8 ? smem + (buf ^ 1) * PBUF : pb, nab, nxv, 0);
+            if constexpr (N64) {
+                kstep(1, wlds + slot1 * WSLOT, t == 8 ? smem + (buf ^ 1) * PBUF : pb, nab, nxv, ka);
+            } else {
+                kstep(0, wb, pb, ab, xv, 3);
+                kstep(1, wlds + slot1 * WSLOT, t == 8 ? smem + (buf ^ 1) * PBUF : pb, nab, nxv, 0);
+            }
             ++s;
             slot = slot1;
         }
@@ -280,6 +297,97 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
     wait_vm<0>();                       // the out-of-range requests of the last steps still write (zeros) into LDS
     __builtin_amdgcn_s_barrier();
     DC_STAMP(4);
+
+    if constexpr (N64) {
+        // ---- 64-channel form: add the two partial blocks of each pixel group, then every wave finishes 32 pixels.
+        // Wave (wm, wk) keeps pixel block wk and hands block 1 - wk to its partner wave ^ 4: 32 registers per lane.
+        constexpr int SROW = 64 + 8;
+        const int wk = wn;
+        float keep[2][16];
+        {
+            float* xch = reinterpret_cast<float*>(smem);                  // [wave][32 registers][64 lanes]
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    xch[(wave * 32 + i * 16 + r) * 64 + lane] = wk ? acc[i][0][r] : acc[i][1][r];
+                    keep[i][r] = wk ? acc[i][1][r] : acc[i][0][r];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep[i][r] += xch[((wave ^ 4) * 32 + i * 16 + r) * 64 + lane];
+            __syncthreads();                                              // the staging below reuses this memory
+        }
+        const int n0 = nt * 64;
+        if (a.bias) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + i * 32 + 8 * rg + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) keep[i][4 * rg + e] += bv[e];
+                }
+        }
+        float ssq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ssq = fmaf(keep[i][r], keep[i][r], ssq);
+        ssq = xhalf_add(ssq);
+        const float rinv = a.norm_scale / fmaxf(sqrtf(ssq), 1e-12f);
+        __bf16* stg = reinterpret_cast<__bf16*>(smem) + wave * 32 * SROW;
+        const int srow0 = lane >> 3, schunk = lane & 7;
+        const long long row0 = (long long)tile * 256 + wm * 64 + wk * 32;
+        if (a.res) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = k * 8 + srow0;
+                bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (row0 + row < a.rows) rv = *reinterpret_cast<const bf16x8*>(a.res + (row0 + row) * a.ld_res + n0 + schunk * 8);
+                *reinterpret_cast<bf16x8*>(stg + row * SROW + schunk * 8) = rv;
+            }
+        }
+        const int frame = NF > 1 ? f0 + wm : f0;
+        const int b = frame / a.fpb;
+        const bool bok = frame < a.frames;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int ch = n0 + i * 32 + 8 * rg + 4 * h;
+                f32x4 gv = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+                if (bok) {
+                    gv = *reinterpret_cast<const f32x4*>(a.gain + b * a.gain_bs + ch);
+                    if (a.shift) sv = *reinterpret_cast<const f32x4*>(a.shift + b * a.shift_bs + ch);
+                }
+                __bf16* sp = stg + l31 * SROW + i * 32 + 8 * rg + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(fmaf(keep[i][4 * rg + e] * rinv, gv[e], sv[e]));
+                if (a.res) {
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(sp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+                *reinterpret_cast<bf16x4*>(sp) = o;
+            }
+        // (a wave reads back only what it wrote itself: no barrier)
+        __bf16* op = a.out + n0 + schunk * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = k * 8 + srow0;
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(stg + row * SROW + schunk * 8);
+            if (row0 + row < a.rows) *reinterpret_cast<bf16x8*>(op + (row0 + row) * a.ldo) = ov;
+        }
+        DC_STAMP(5);
+        return;
+    }
 
     // ---- epilogue: + bias (share 0) [NORM: RMSNorm, gain / shift, SiLU, residual], bf16, transposed through LDS so that
     // 8 lanes store one pixel's 128 contiguous bytes
@@ -390,6 +498,7 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
 
 int g_dc_enabled = -1;
 int g_dc_norm_all = 0;      // tests: the normalisation epilogue on every image width the kernel is built for
+int g_dc_n64 = -1;          // the 64-output-channel form: off unless VDMI_DCONV_N64=1 (it lost to the tap-GEMM, see below)
 
 bool dc_covers(const vdmi_tapgemm_args& A) {
     if (g_dc_enabled < 0) {
@@ -397,17 +506,28 @@ bool dc_covers(const vdmi_tapgemm_args& A) {
         g_dc_enabled = (e && e[0] == '0') ? 0 : 1;
     }
     if (!g_dc_enabled) return false;
+    if (g_dc_n64 < 0) {
+        // measured per launch of 8 samples on 64x64 images (128 -> 64 channels): 76-78 us against the tap-GEMM's 67-68,
+        // and 3.86 against 3.65 ms per denoise step: with 8 MFMAs per wave between barriers and one workgroup per CU the
+        // per-step synchronisation and the partial-sum exchange cost more than the 64 x 64 wave tiles save
+        const char* e = std::getenv("VDMI_DCONV_N64");
+        g_dc_n64 = (e && e[0] == '1') ? 1 : 0;
+    }
     const vdmi_tap_pass& m = A.main;
     const bool norm = A.epilogue == VDMI_EPI_NORM_SILU;
     if (norm) {
         // the tile must hold every output channel of its pixels; residual: none or an identity tensor
-        if (A.n != 128 || A.has_res == 1 || !A.gain || A.frames_per_batch <= 0 || A.k_split > 1) return false;
+        if ((A.n != 128 && A.n != 64) || A.has_res == 1 || !A.gain || A.frames_per_batch <= 0 || A.k_split > 1) return false;
+        // 64 output channels: the form that splits the contraction over the wave groups; more than one input chunk
+        // (the 64 -> 64 layers of these images are the weight-stationary kernel's)
+        if (A.n == 64 && (g_dc_n64 == 0 || A.main.c0 + A.main.c1 < 128)) return false;
         // measured per launch of 8 samples: 32-pixel-wide images 42-45 -> 40-44 us, smaller images (80-tile launches)
         // 17-18 -> 18-19 us against the tap-GEMM's fused epilogue: only the former take this kernel.  (The choice
         // depends on the layer's shape alone, never on the batch.)
         if (A.main.in_w != 32 && A.main.in_w != 64 && !g_dc_norm_all) return false;
         if (A.has_res == 2 && (!A.res_identity || A.ld_res % 8 || !aligned16(A.res_identity))) return false;
         if (A.gain_bstride % 4 || A.shift_bstride % 4 || !aligned16(A.gain) || (A.shift && !aligned16(A.shift))) return false;
+        if (A.n == 64 && A.main.in_w != 32 && A.main.in_w != 64 && !g_dc_norm_all) return false;
     } else if (A.epilogue != VDMI_EPI_PLAIN || A.act || A.has_res || A.n % 128 || A.tile_bn != 64) {
         return false;
     }
@@ -433,7 +553,12 @@ bool dc_covers(const vdmi_tapgemm_args& A) {
 
 }   // namespace
 
-extern "C" void vdmi_dconv_enable(int on) { g_dc_enabled = on ? 1 : 0; g_dc_norm_all = on > 1; }
+extern "C" void vdmi_dconv_enable(int on) {
+    g_dc_enabled = on ? 1 : 0;
+    g_dc_norm_all = on > 1;
+    if (on > 1) g_dc_n64 = 1;           // tests: every form the kernel is built for
+    else if (g_dc_n64 > 0) g_dc_n64 = -1;   // back to what the environment says
+}
 extern "C" int vdmi_dconv_covers(const vdmi_tapgemm_args* a) { return a && dc_covers(*a) ? 1 : 0; }
 
 // Runs `A` on the streaming kernel when the launch has its shape.  Returns VDMI_OK when it was launched, 1 when the
@@ -455,14 +580,15 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     k.nch = k.nch0 + m.c1 / 64;
     k.ldo = A.ldo;
     k.n = A.n;
-    k.npad32 = A.n / 32;            // n is a multiple of 128: packed without padding for 64-channel tiles
+    k.npad32 = A.n / 32;            // n is a multiple of 64: packed without padding for 64-channel tiles
     k.H = H;
     k.frames = A.frames;
     k.rows = (long long)A.frames * H * W;
     const int R = W == 8 ? 8 : (W == 16 ? 16 : (W == 32 ? 8 : 4));
     k.bands = H / R;
     k.npx = W == 8 ? (A.frames + 3) / 4 : A.frames * k.bands;
-    k.nnt = A.n / 128;
+    const bool n64 = A.n == 64;
+    k.nnt = n64 ? 1 : A.n / 128;
     k.ksplit = A.k_split > 1 ? A.k_split : 1;
     k.src0_bytes = (unsigned)(k.rows * m.c0 * 2);
     k.src1_bytes = m.c1 ? (unsigned)(k.rows * m.c1 * 2) : 0u;
@@ -483,11 +609,11 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     const long long nwg = (long long)k.npx * k.nnt * k.ksplit;
     if (nwg > 0x7fffffffLL) return VDMI_E_SHAPE;
 
-    static std::atomic<uint64_t> attr_mask[8];
+    static std::atomic<uint64_t> attr_mask[12];
     const int PW = W + 2, PR = R + 2, NF = 256 / (R * W);
     const int npiece = (NF * PR * PW + 7) / 8;
-    const size_t lds = (size_t)2 * npiece * 1024 + 3 * 16384;
-    const size_t stg = (size_t)8 * 64 * 72 * 2 + 2 * 256 * 4;
+    const size_t lds = (size_t)2 * npiece * 1024 + 3 * (n64 ? 8192 : 16384);
+    const size_t stg = n64 ? (size_t)8 * 32 * 64 * 4 : (size_t)8 * 64 * 72 * 2 + 2 * 256 * 4;   // exchange / staging after the loop
     const size_t need = lds > stg ? lds : stg;
 #define VDMI_DC_CASE(W_, R_, NORM_, IDX_)                                                                          \
     {                                                                                                              \
@@ -495,11 +621,22 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
         if (vdmi_set_max_lds(reinterpret_cast<const void*>(fn), attr_mask[IDX_], 160 * 1024)) return VDMI_E_LAUNCH; \
         hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(512), need, stream, k);                                   \
     }
+#define VDMI_DC_CASE64(W_, R_, IDX_)                                                                               \
+    {                                                                                                              \
+        auto fn = dconv_kernel<W_, R_, true, true>;                                                                \
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(fn), attr_mask[IDX_], 160 * 1024)) return VDMI_E_LAUNCH; \
+        hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(512), need, stream, k);                                   \
+    }
+    if (n64) {
+        if (W == 8) VDMI_DC_CASE64(8, 8, 8) else if (W == 16) VDMI_DC_CASE64(16, 16, 9)
+        else if (W == 32) VDMI_DC_CASE64(32, 8, 10) else VDMI_DC_CASE64(64, 4, 11)
+    } else
     if (W == 8) { if (norm) VDMI_DC_CASE(8, 8, true, 0) else VDMI_DC_CASE(8, 8, false, 1) }
     else if (W == 16) { if (norm) VDMI_DC_CASE(16, 16, true, 2) else VDMI_DC_CASE(16, 16, false, 3) }
     else if (W == 32) { if (norm) VDMI_DC_CASE(32, 8, true, 4) else VDMI_DC_CASE(32, 8, false, 5) }
     else { if (norm) VDMI_DC_CASE(64, 4, true, 6) else VDMI_DC_CASE(64, 4, false, 7) }
 #undef VDMI_DC_CASE
+#undef VDMI_DC_CASE64
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
