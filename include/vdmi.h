@@ -540,7 +540,13 @@ int vdmi_layernorm_rows_bwd(const void* x, const void* dxh, const void* add, voi
  * attention over the positions of a frame (vdp.py:708-710; b = frames, f = positions, no rotary, no bias).
  * Backward: from qkv, o, lse and dout (gradient of o) the gradient of the raw qkv rows (dqkv, same layout) and of the
  * bias (dbias float [heads][f][f], ACCUMULATED; may be NULL).  focus: uint8 [b] or NULL - the focus-present mask of
- * vdp.py:590-600: in a flagged sample every frame attends to itself only (scores off the diagonal are masked). */
+ * vdp.py:590-600: in a flagged sample every frame attends to itself only (scores off the diagonal are masked).
+ * Frame axes of up to 32 run on the matrix cores (tiles of 32 tokens = 32 / f whole sites, one wave per (tile, head);
+ * the rotated q and k, the probabilities and the score gradients are rounded to the storage type as matrix operands);
+ * that form sums the bias gradient in registers and needs `workspace` (vdmi_tattn_core_bwd_workspace_bytes() bytes of
+ * device memory, 16-byte aligned, contents irrelevant) for the per-wave partial sums, which a second launch adds in a
+ * fixed order.  Without a workspace, and for longer axes, the backward is the vector kernel, whose bias gradient uses
+ * float atomics.  VDMI_TATTN_CORE_MFMA=0 / vdmi_tattn_core_mfma_enable(0) keep every call on the vector kernels. */
 /* HOST. 1 when vdmi_tattn_core_fwd (bwd = 0) / vdmi_tattn_core_bwd (bwd = 1; with_dbias: a relative-position-bias
  * gradient is asked for) can run a token axis of f positions with `heads` heads: the site's tiles and, in the
  * backward, the bias-gradient table [heads][f][f] must fit 160 KiB of LDS (with 8 heads the backward ends near
@@ -551,7 +557,11 @@ int vdmi_tattn_core_fwd(const void* qkv, void* o, float* lse, const float* bias,
                         vdmi_stream stream);
 int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* dbias,
                         const float* bias, const float* rot_cos, const float* rot_sin, const uint8_t* focus, int b, int f,
-                        int hw, int heads, float scale, vdmi_stream stream);
+                        int hw, int heads, float scale, void* workspace, vdmi_stream stream);
+/* HOST. Bytes of `workspace` for that shape (0 when the shape runs on the vector kernel). */
+size_t vdmi_tattn_core_bwd_workspace_bytes(int b, int f, int hw, int heads);
+/* HOST. Tests / A-B runs: 0 keeps the attention cores on the vector kernels, 1 allows the matrix-core form again. */
+void vdmi_tattn_core_mfma_enable(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Training kernels of Residual(PreNorm(SpatialLinearAttention)) (vdp.py:454-479), forward and backward, on the RAW rows of

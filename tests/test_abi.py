@@ -218,8 +218,11 @@ def test_attention_training_entry_points_reject_bad_arguments():
     assert lib.vdmi_tattn_core_fwd(None, 16, 16, None, None, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG
     assert lib.vdmi_tattn_core_fwd(16, 16, 16, None, None, None, None, 1, 257, 64, 8, 0.17, None) == E_SHAPE   # f > 256
     assert lib.vdmi_tattn_core_fwd(16, 16, 16, None, 16, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG        # cos without sin
-    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, 16, None, None, None, None, 1, 10, 64, 8, 0.17, None) == E_ARG   # dbias, no bias
-    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, None, None, None, None, None, 1, 300, 64, 8, 0.17, None) == E_SHAPE  # f > 256
+    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, 16, None, None, None, None, 1, 10, 64, 8, 0.17, None, None) == E_ARG   # dbias, no bias
+    assert lib.vdmi_tattn_core_bwd(16, 16, 16, 16, 16, None, None, None, None, None, 1, 300, 64, 8, 0.17, None, None) == E_SHAPE  # f > 256
+    # matrix-core form: 22 tiles of 3 sites x 8 heads = 176 units -> 22 workgroups, rounded to a multiple of the heads
+    assert lib.vdmi_tattn_core_bwd_workspace_bytes(1, 10, 64, 8) == 24 * 8 * 4096
+    assert lib.vdmi_tattn_core_bwd_workspace_bytes(1, 33, 64, 8) == 0                           # vector kernel
     assert lib.vdmi_sla_train_partial_bytes(16, 4096, 4) == 16 * 4 * 4 * (1024 + 64) * 4
     assert lib.vdmi_sla_train_combined_bytes(16, 4) == 16 * 4 * (1024 + 64) * 4
     assert lib.vdmi_sla_train_partial_bytes(16, 4096, 3) == 0                                   # 256 % heads

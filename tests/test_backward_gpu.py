@@ -288,13 +288,29 @@ def _attn_core_ref(qkv, bias, cos, sin, b, f, hw, heads, scale, focus=None):
     return out.permute(0, 3, 1, 2, 4).reshape(b * f * hw, hid)
 
 
+@pytest.mark.parametrize("form", ["mfma", "vector"])
 @pytest.mark.parametrize("b,f,hw,heads,rotary,with_bias,focus", [
     (2, 10, 37, 8, True, True, None), (1, 16, 64, 8, True, True, None), (3, 5, 20, 4, False, False, None),
     (1, 32, 9, 8, True, True, None), (3, 256, 1, 8, False, False, None), (2, 64, 1, 8, False, False, None),
-    (3, 10, 37, 8, True, True, (True, False, True)), (2, 6, 16, 4, False, True, (True, True))])
-def test_tattn_core_forward_backward_vs_torch(b, f, hw, heads, rotary, with_bias, focus):
+    (3, 10, 37, 8, True, True, (True, False, True)), (2, 6, 16, 4, False, True, (True, True)),
+    (2, 7, 11, 3, True, True, None), (1, 16, 1031, 8, True, True, None), (2, 17, 5, 8, True, False, None),
+    (1, 1, 40, 8, False, False, None)])
+def test_tattn_core_forward_backward_vs_torch(b, f, hw, heads, rotary, with_bias, focus, form):
+    """vdmi_tattn_core_fwd / _bwd against double-precision torch ops, on the matrix-core form (frame axes up to 32: tiles
+    of 32 / f sites, also with a ragged last tile, 3 heads, one frame) and on the vector kernels (every length)."""
     from video_diffusion_amd import _lib
     lib = _lib.lib()
+    if form == "mfma" and f > 32:
+        pytest.skip("frame axes beyond 32 run on the vector kernels only")
+    lib.vdmi_tattn_core_mfma_enable(1 if form == "mfma" else 0)
+    try:
+        _tattn_core_case(lib, b, f, hw, heads, rotary, with_bias, focus, form)
+    finally:
+        lib.vdmi_tattn_core_mfma_enable(1)
+
+
+def _tattn_core_case(lib, b, f, hw, heads, rotary, with_bias, focus, form):
+    from video_diffusion_amd import _lib
     g = torch.Generator().manual_seed(10)
     rows, hid = b * f * hw, heads * 32
     qkv = _bf(torch.randn(rows, 3 * hid, generator=g)).to(DEV)
@@ -311,13 +327,17 @@ def test_tattn_core_forward_backward_vs_torch(b, f, hw, heads, rotary, with_bias
                                        b, f, hw, heads, scale, None))
     dqkv = torch.empty_like(qkv)
     dbias = torch.zeros_like(bias) if with_bias else None
+    ws_bytes = lib.vdmi_tattn_core_bwd_workspace_bytes(b, f, hw, heads)
+    assert (ws_bytes > 0) == (form == "mfma")
+    ws = torch.empty(max(ws_bytes, 16), device=DEV, dtype=torch.uint8).fill_(0x7f)      # contents must not matter
     _lib.check(lib.vdmi_tattn_core_bwd(qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                       ptr(dbias), ptr(bias), ptr(cos), ptr(sin), ptr(foc), b, f, hw, heads, scale, None))
+                                       ptr(dbias), ptr(bias), ptr(cos), ptr(sin), ptr(foc), b, f, hw, heads, scale,
+                                       ws.data_ptr(), None))
     qr = qkv.double().requires_grad_(True)
     br = bias.double().requires_grad_(True) if with_bias else None
     ref = _attn_core_ref(qr, br, cos, sin, b, f, hw, heads, scale, None if foc is None else foc.bool())
     ref.backward(dout.double())
-    tag = f"tattn_core.f{f}.h{heads}" + ("" if focus is None else ".focus")
+    tag = f"tattn_core.{form}.f{f}.hw{hw}.h{heads}" + ("" if focus is None else ".focus")
     assert record(tag + ".o", rel_err(o.float().cpu(), ref.detach().cpu()), 5e-3) < 5e-3
     assert record(tag + ".dqkv", rel_err(dqkv.float().cpu(), qr.grad.cpu()), 1e-2) < 1e-2
     if with_bias:

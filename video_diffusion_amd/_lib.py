@@ -179,7 +179,9 @@ _SIGNATURES = {
     "vdmi_layernorm_rows_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "vdmi_tattn_core_fits": (C.c_int, [C.c_int] * 4),
     "vdmi_tattn_core_fwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
-    "vdmi_tattn_core_bwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "vdmi_tattn_core_bwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),
+    "vdmi_tattn_core_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "vdmi_tattn_core_mfma_enable": (None, [C.c_int]),
     "vdmi_sla_train_partial_bytes": (C.c_size_t, [C.c_int] * 3),
     "vdmi_sla_train_combined_bytes": (C.c_size_t, [C.c_int] * 2),
     "vdmi_sla_train_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] +

@@ -377,6 +377,18 @@ int core_launch(bool bwd, CoreArgs& a, hipStream_t stream) {
     return VDMI_OK;
 }
 
+}   // namespace
+
+// tattn_core_mfma.hip: the matrix-core form for frame axes of up to 32
+bool vdmi_tattn_core_mfma_covers(int b, int f, int hw, int heads);
+size_t vdmi_tattn_core_mfma_workspace(int b, int f, int hw, int heads);
+int vdmi_tattn_core_mfma_launch(bool bwd, const void* qkv, const void* o, const void* dout, const float* lse, void* out,
+                                float* lse_out, float* dbias, void* workspace, const float* bias, const float* rot_cos,
+                                const float* rot_sin, const unsigned char* focus, int b, int f, int hw, int heads,
+                                float scale, hipStream_t stream);
+
+namespace {
+
 int ln_check(const void* x, const void* out, int64_t rows, int c) {
     if (!x || !out) return VDMI_E_ARG;
     if (rows <= 0 || c < 64 || c > 2048 || !pow2i(c)) return VDMI_E_SHAPE;
@@ -388,6 +400,10 @@ int ln_check(const void* x, const void* out, int64_t rows, int c) {
 
 extern "C" int vdmi_tattn_core_fits(int bwd, int f, int heads, int with_dbias) {
     return core_split(bwd != 0, f, heads, with_dbias != 0, nullptr, nullptr, nullptr) ? 1 : 0;
+}
+
+extern "C" size_t vdmi_tattn_core_bwd_workspace_bytes(int b, int f, int hw, int heads) {
+    return vdmi_tattn_core_mfma_covers(b, f, hw, heads) ? vdmi_tattn_core_mfma_workspace(b, f, hw, heads) : 0;
 }
 
 extern "C" int vdmi_layernorm_rows(const void* x, void* xh, int64_t rows, int c, float eps, vdmi_stream stream) {
@@ -423,6 +439,10 @@ extern "C" int vdmi_tattn_core_fwd(const void* qkv, void* o, float* lse, const f
                                    vdmi_stream stream) {
     if (!qkv || !o || !lse) return VDMI_E_ARG;
     if (!aligned16(qkv) || !aligned16(o)) return VDMI_E_ALIGN;
+    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return VDMI_E_ARG;
+    if (vdmi_tattn_core_mfma_covers(b, f, hw, heads))
+        return vdmi_tattn_core_mfma_launch(false, qkv, nullptr, nullptr, nullptr, o, lse, nullptr, nullptr, bias, rot_cos,
+                                           rot_sin, focus, b, f, hw, heads, scale, static_cast<hipStream_t>(stream));
     CoreArgs a{};
     a.qkv = static_cast<const __bf16*>(qkv);
     a.out = static_cast<__bf16*>(o);
@@ -434,10 +454,17 @@ extern "C" int vdmi_tattn_core_fwd(const void* qkv, void* o, float* lse, const f
 
 extern "C" int vdmi_tattn_core_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
                                    float* dbias, const float* bias, const float* rot_cos, const float* rot_sin,
-                                   const uint8_t* focus, int b, int f, int hw, int heads, float scale, vdmi_stream stream) {
+                                   const uint8_t* focus, int b, int f, int hw, int heads, float scale, void* workspace,
+                                   vdmi_stream stream) {
     if (!qkv || !o || !dout || !lse || !dqkv) return VDMI_E_ARG;
     if (dbias && !bias) return VDMI_E_ARG;
     if (!aligned16(qkv) || !aligned16(o) || !aligned16(dout) || !aligned16(dqkv)) return VDMI_E_ALIGN;
+    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return VDMI_E_ARG;
+    // the matrix-core form keeps its bias-gradient partial sums in the workspace; without one the vector form (which
+    // accumulates with atomics) serves a call that wants the bias gradient
+    if (vdmi_tattn_core_mfma_covers(b, f, hw, heads) && (!dbias || (workspace && aligned16(workspace))))
+        return vdmi_tattn_core_mfma_launch(true, qkv, o, dout, lse, dqkv, nullptr, dbias, workspace, bias, rot_cos, rot_sin,
+                                           focus, b, f, hw, heads, scale, static_cast<hipStream_t>(stream));
     CoreArgs a{};
     a.qkv = static_cast<const __bf16*>(qkv);
     a.o = static_cast<const __bf16*>(o);

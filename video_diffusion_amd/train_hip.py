@@ -602,9 +602,11 @@ class TemporalAttnFn(torch.autograd.Function):
         # attention core
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias_c) if (bias_c is not None and need[4]) else None
+        ws_bytes = lib.vdmi_tattn_core_bwd_workspace_bytes(*core, heads) if dbias is not None else 0
+        ws = torch.empty(ws_bytes, device=qkv.device, dtype=torch.uint8) if ws_bytes else None
         check(lib.vdmi_tattn_core_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                      ptr(dbias), ptr(bias_c), ptr(cos), ptr(sin), ptr(foc), *core, heads, scale, _stream()),
-              "vdmi_tattn_core_bwd")
+                                      ptr(dbias), ptr(bias_c), ptr(cos), ptr(sin), ptr(foc), *core, heads, scale, ptr(ws),
+                                      _stream()), "vdmi_tattn_core_bwd")
         # to_qkv (with the folded gamma), LayerNorm, residual
         dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
         dwqkv = dgamma = None
