@@ -56,7 +56,7 @@ struct McArgs {
     const float* lse;       // bwd: [rows][heads], natural log
     __bf16* out;            // fwd: o rows; bwd: dqkv rows
     float* lse_out;         // fwd
-    float* dbias_part;      // bwd: [waves][32 keys][32 queries] or null
+    float* dbias_part;      // bwd: [waves][32 queries][32 keys] or null
     const float* bias;      // [heads][f][f] or null
     const float* rot_cos;   // [f][16] or null
     const float* rot_sin;
@@ -71,6 +71,8 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
     // per wave: transposition images (fwd: V; bwd: K, Q, dO) and, bwd, log-sum-exp and delta by token
     __shared__ __attribute__((aligned(16))) char img[MC_WAVES][BWD ? 3 : 1][32 * 64];
     __shared__ __attribute__((aligned(16))) float stats[BWD ? MC_WAVES : 1][2][32];
+    // bwd: the bias in both orientations, [orientation][register / 4][lane] float4 (registers go to the next unit's rows)
+    __shared__ __attribute__((aligned(16))) f32x4 btab[BWD ? MC_WAVES : 1][2][4][64];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int F = a.f, H = a.heads, ld = 3 * H * 32, ldo = H * 32;
@@ -99,13 +101,17 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
     const long long wave_gid = (long long)blockIdx.x * MC_WAVES + wave, stride = (long long)gridDim.x * MC_WAVES;
     const int head = (int)(wave_gid % H);               // the same for every unit of this wave: stride % heads == 0
     // bias in the log2 domain: [key register][query lane] and, bwd, [query register][key lane]
-    f32x16 bT, bS;
+    f32x16 bT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int fj = acc_row(r, half) % F;
         const bool on = a.bias && in_tile;
         bT[r] = on ? a.bias[((long long)head * F + fi) * F + fj] * LOG2E : 0.f;
-        bS[r] = (BWD && on) ? a.bias[((long long)head * F + fj) * F + fi] * LOG2E : 0.f;
+        if constexpr (BWD) {
+            const float bs = on ? a.bias[((long long)head * F + fj) * F + fi] * LOG2E : 0.f;
+            reinterpret_cast<float*>(&btab[wave][0][r >> 2][lane])[r & 3] = bT[r];
+            reinterpret_cast<float*>(&btab[wave][1][r >> 2][lane])[r & 3] = bs;
+        }
     }
     f32x16 dbacc;
 #pragma unroll
@@ -146,28 +152,56 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
         }
     };
 
-    for (long long u = wave_gid; u < a.units; u += stride) {
+    // One unit's rows, requested one unit ahead of their use (the loads of unit u + 1 are in flight during the products
+    // of unit u; with only the wave's own loads outstanding a unit would cost a full memory round trip).
+    struct Unit {
+        bf16x8 q0, q1, k0, k1, v0, v1, g0, g1, o0, o1;
+        float lse;
+        long long row;
+        bool ok, foc;
+    };
+    auto fetch = [&](long long u, Unit& n) {
         const long long tile = u / H;
         const long long site = tile * a.g + slot;
-        const bool ok = in_tile && site < a.nsites;
-        const long long bb = ok ? site / a.hw : 0, sp = ok ? site - bb * a.hw : 0;
-        const long long row = (bb * F + fi) * a.hw + sp;
-        const bool foc = a.focus && ok && a.focus[bb] != 0;
-        const unsigned mask = ok ? (foc ? mask_self : mask_same) : 0u;
-
-        bf16x8 q0 = zero8, q1 = zero8, k0 = zero8, k1 = zero8, v0 = zero8, v1 = zero8;
-        if (ok) {
-            const __bf16* p = a.qkv + row * ld + head * 32 + 8 * half;
-            q0 = *reinterpret_cast<const bf16x8*>(p);
-            q1 = *reinterpret_cast<const bf16x8*>(p + 16);
-            k0 = *reinterpret_cast<const bf16x8*>(p + ldo);
-            k1 = *reinterpret_cast<const bf16x8*>(p + ldo + 16);
-            v0 = *reinterpret_cast<const bf16x8*>(p + 2 * ldo);
-            v1 = *reinterpret_cast<const bf16x8*>(p + 2 * ldo + 16);
+        n.ok = in_tile && u < a.units && site < a.nsites;
+        const long long bb = n.ok ? site / a.hw : 0, sp = n.ok ? site - bb * a.hw : 0;
+        n.row = (bb * F + fi) * a.hw + sp;
+        n.foc = a.focus && n.ok && a.focus[bb] != 0;
+        n.q0 = n.q1 = n.k0 = n.k1 = n.v0 = n.v1 = zero8;
+        if constexpr (BWD) { n.g0 = n.g1 = n.o0 = n.o1 = zero8; n.lse = 0.f; }
+        if (n.ok) {
+            const __bf16* p = a.qkv + n.row * ld + head * 32 + 8 * half;
+            n.q0 = *reinterpret_cast<const bf16x8*>(p);
+            n.q1 = *reinterpret_cast<const bf16x8*>(p + 16);
+            n.k0 = *reinterpret_cast<const bf16x8*>(p + ldo);
+            n.k1 = *reinterpret_cast<const bf16x8*>(p + ldo + 16);
+            n.v0 = *reinterpret_cast<const bf16x8*>(p + 2 * ldo);
+            n.v1 = *reinterpret_cast<const bf16x8*>(p + 2 * ldo + 16);
+            if constexpr (BWD) {
+                const __bf16* gp = a.dout + n.row * ldo + head * 32 + 8 * half;
+                const __bf16* op = a.o + n.row * ldo + head * 32 + 8 * half;
+                n.g0 = *reinterpret_cast<const bf16x8*>(gp);
+                n.g1 = *reinterpret_cast<const bf16x8*>(gp + 16);
+                n.o0 = *reinterpret_cast<const bf16x8*>(op);
+                n.o1 = *reinterpret_cast<const bf16x8*>(op + 16);
+                n.lse = a.lse[n.row * H + head];
+            }
         }
+    };
+
+    Unit nx;
+    fetch(wave_gid, nx);
+    for (long long u = wave_gid; u < a.units; u += stride) {
+        const Unit c = nx;
+        fetch(u + stride, nx);
+        const bool ok = c.ok, foc = c.foc;
+        const long long row = c.row;
+        const unsigned mask = ok ? (foc ? mask_self : mask_same) : 0u;
+        bf16x8 q0 = c.q0, q1 = c.q1, k0 = c.k0, k1 = c.k1;
+        const bf16x8 v0 = c.v0, v1 = c.v1;
+        rotate(q0, q1, a.scale * LOG2E);
+        rotate(k0, k1, 1.f);
         if constexpr (!BWD) {
-            rotate(q0, q1, a.scale * LOG2E);
-            rotate(k0, k1, 1.f);
             to_image(img[wave][0], v0, v1);
             f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, bT, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q1, st, 0, 0, 0);
@@ -205,21 +239,12 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
                 if (half == 0) a.lse_out[row * H + head] = (m + __builtin_amdgcn_logf(l)) * LN2;
             }
         } else {
-            bf16x8 g0 = zero8, g1 = zero8;
-            float delta = 0.f, lse2 = 0.f;
-            if (ok) {
-                const __bf16* gp = a.dout + row * ldo + head * 32 + 8 * half;
-                const __bf16* op = a.o + row * ldo + head * 32 + 8 * half;
-                g0 = *reinterpret_cast<const bf16x8*>(gp);
-                g1 = *reinterpret_cast<const bf16x8*>(gp + 16);
-                const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(op), o1 = *reinterpret_cast<const bf16x8*>(op + 16);
+            const bf16x8 g0 = c.g0, g1 = c.g1;
+            float delta = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) delta += (float)g0[e] * (float)o0[e] + (float)g1[e] * (float)o1[e];
-                lse2 = a.lse[row * H + head] * LOG2E;
-            }
+            for (int e = 0; e < 8; ++e) delta += (float)g0[e] * (float)c.o0[e] + (float)g1[e] * (float)c.o1[e];
             delta = xhalf_add(delta);
-            rotate(q0, q1, a.scale * LOG2E);
-            rotate(k0, k1, 1.f);
+            const float lse2 = c.lse * LOG2E;
             to_image(img[wave][0], k0, k1);
             to_image(img[wave][1], q0, q1);
             to_image(img[wave][2], g0, g1);
@@ -231,7 +256,11 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
             {
                 f32x16 seed, negd;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { seed[r] = bT[r] - lse2; negd[r] = -delta; }
+                for (int rg = 0; rg < 4; ++rg) {
+                    const f32x4 b4 = btab[wave][0][rg][lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { seed[4 * rg + e] = b4[e] - lse2; negd[4 * rg + e] = -delta; }
+                }
                 f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, seed, 0, 0, 0);
                 f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, g0, negd, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q1, st, 0, 0, 0);
@@ -257,10 +286,11 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
                 f32x16 seed, negd;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
+                    const f32x4 b4 = btab[wave][1][rg][lane];
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(&stats[wave][0][8 * rg + 4 * half]);
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(&stats[wave][1][8 * rg + 4 * half]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { seed[4 * rg + e] = bS[4 * rg + e] - l4[e]; negd[4 * rg + e] = -d4[e]; }
+                    for (int e = 0; e < 4; ++e) { seed[4 * rg + e] = b4[e] - l4[e]; negd[4 * rg + e] = -d4[e]; }
                 }
                 f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, k0, seed, 0, 0, 0);
                 f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, v0, negd, 0, 0, 0);
@@ -299,15 +329,16 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
     }
     if constexpr (BWD) {
         if (a.dbias_part) {
-            float* dst = a.dbias_part + wave_gid * 1024 + l31;
+            float* dst = a.dbias_part + wave_gid * 1024 + l31 * 32 + 4 * half;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[acc_row(r, half) * 32] = dbacc[r];
+            for (int rg = 0; rg < 4; ++rg)
+                *reinterpret_cast<f32x4*>(dst + 8 * rg) = f32x4{dbacc[4 * rg], dbacc[4 * rg + 1], dbacc[4 * rg + 2], dbacc[4 * rg + 3]};
         }
     }
 }
 
 // dbias[h][i][j] += sum over the waves of head h (wave % heads == h) and the g diagonal blocks of their partials
-// [key token][query token]; one workgroup per (h, i), eight interleaved chains of waves added in a fixed order
+// [query token][key token]; one workgroup per (h, i), eight interleaved chains of waves added in a fixed order
 __global__ __launch_bounds__(256) void tattn_core_dbias_kernel(const float* __restrict__ part, float* __restrict__ dbias,
                                                                int f, int heads, int g, long long nwaves) {
     __shared__ float red[8][32];
@@ -315,9 +346,11 @@ __global__ __launch_bounds__(256) void tattn_core_dbias_kernel(const float* __re
     const int j = threadIdx.x & 31, chain = threadIdx.x >> 5;
     float s = 0.f;
     if (j < f) {
-        for (long long w = h + (long long)heads * chain; w < nwaves; w += (long long)heads * 8) {
+        const long long step = (long long)heads * 8;
+#pragma unroll 8
+        for (long long w = h + (long long)heads * chain; w < nwaves; w += step) {
             const float* p = part + w * 1024;
-            for (int sl = 0; sl < g; ++sl) s += p[(sl * f + j) * 32 + sl * f + i];
+            for (int sl = 0; sl < g; ++sl) s += p[(sl * f + i) * 32 + sl * f + j];
         }
     }
     red[chain][j] = s;
@@ -332,13 +365,14 @@ __global__ __launch_bounds__(256) void tattn_core_dbias_kernel(const float* __re
 
 int g_mc_enabled = -1;
 
-// workgroups of a launch: enough for every (tile, heads) unit up to two rounds of the chip, a multiple of `heads` so that
-// a wave's units all have one head
-long long mc_grid(int b, int f, int hw, int heads) {
+// workgroups of a launch: one wave per (tile, head) unit up to what the chip holds at once, a multiple of `heads` so
+// that a wave's units all have one head
+long long mc_grid(bool bwd, int b, int f, int hw, int heads) {
     const int g = 32 / f;
     const long long nsites = (long long)b * hw, tiles = (nsites + g - 1) / g, units = tiles * heads;
     long long grid = (units + MC_WAVES - 1) / MC_WAVES;
-    if (grid > 512) grid = 512;
+    const long long cap = bwd ? 256 : 512;              // workgroups the chip holds at once (registers: one / two per CU)
+    if (grid > cap) grid = cap;
     grid = (grid + heads - 1) / heads * heads;
     return grid;
 }
@@ -359,7 +393,7 @@ bool vdmi_tattn_core_mfma_covers(int b, int f, int hw, int heads) {
 }
 
 size_t vdmi_tattn_core_mfma_workspace(int b, int f, int hw, int heads) {
-    return (size_t)mc_grid(b, f, hw, heads) * MC_WAVES * 1024 * sizeof(float);
+    return (size_t)mc_grid(true, b, f, hw, heads) * MC_WAVES * 1024 * sizeof(float);
 }
 
 // fwd: o, lse_out set; bwd: o, dout, lse, dqkv set, dbias with its workspace or neither
@@ -380,7 +414,7 @@ int vdmi_tattn_core_mfma_launch(bool bwd, const void* qkv, const void* o, const 
     a.nsites = (long long)b * hw;
     a.units = (a.nsites + a.g - 1) / a.g * heads;
     a.scale = scale;
-    const long long grid = mc_grid(b, f, hw, heads);
+    const long long grid = mc_grid(bwd, b, f, hw, heads);
     if (bwd) {
         hipLaunchKernelGGL(tattn_core_mfma_kernel<true>, dim3((unsigned)grid), dim3(MC_WAVES * 64), 0, stream, a);
         if (dbias)
