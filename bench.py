@@ -100,13 +100,20 @@ def train_step_line(device, steps=5, torch_leg=False):
     noise = torch.randn_like(x)
     t = torch.randint(0, TIMESTEPS, (1,), device=device)
 
+    from video_diffusion_amd import train_hip
+    store = train_hip.PackStore()
+
     def step(backend):
         unet.train_backend = backend
         for p in unet.parameters():
             p.grad = None
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            loss = F.l1_loss(unet(x, t).float(), noise)
-        loss.backward()
+        # as in the Trainer's loop: packed weight sets live in a store; every timed step counts as following an optimizer
+        # step (every set stale), so it packs each weight of the model once, in the store's one batched launch
+        store.invalidate()
+        with train_hip.fixed_weights(store):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = F.l1_loss(unet(x, t).float(), noise)
+            loss.backward()
         return loss
 
     out = {"workload": "BASELINE configs[4]: Unet3D(dim=128,dim_mults=(1,2,4,8),channels=3) l1 loss forward + backward on "

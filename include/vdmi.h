@@ -467,6 +467,22 @@ int vdmi_ddpm_step_thres(const float* x, const float* eps, const float* z, const
 int vdmi_pack_taps_device(const float* w, int n, int npad, int cin0, int cin1, int ntaps, int bkc, int transposed,
                           void* out, vdmi_stream stream);
 
+/* Many weight sets in ONE launch (a training step packs every weight of the model again after each optimizer step: some
+ * two hundred sets, most of them a few microseconds of work).  Each job is one vdmi_pack_taps_device call; in_scale
+ * (device float [cin0 + cin1] over the FORWARD weight's input channels, or NULL) multiplies every element by the factor of
+ * its input channel - the LayerNorm gamma that the attention layers fold into to_qkv (vdp.py:386-389, 546) - so the
+ * folded weight never exists as a tensor.  `jobs` is host memory; device_table: vdmi_pack_taps_batch_table_bytes(count)
+ * bytes of device memory that the launch reads (keep it until the stream has passed the call).  Has no counterpart in
+ * the reference (torch keeps one weight layout). */
+typedef struct vdmi_pack_job {
+    const float* w;
+    const float* in_scale;
+    void* out;
+    int n, npad, cin0, cin1, ntaps, bkc, transposed;
+} vdmi_pack_job;
+size_t vdmi_pack_taps_batch_table_bytes(int count);
+int vdmi_pack_taps_batch(const vdmi_pack_job* jobs, int count, void* device_table, vdmi_stream stream);
+
 /* rows bf16 [nf*hw][ld], channel window [c_off, c_off + c)  ->  out bf16 [ceil(nf/16)][ceil(c/32)][hw][32][16]
  * (frame block, channel block, pixel, channel in block, frame in block), frames beyond nf and channels beyond c zero:
  * the operand layout of vdmi_conv_wgrad (the frame is the fast contraction index, so a tap shift never breaks a

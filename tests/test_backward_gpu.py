@@ -614,21 +614,55 @@ def test_long_token_axis_attention_matches_the_explicit_softmax():
 
 
 def test_fixed_weights_store_follows_the_version_counter():
-    """train_hip.fixed_weights: a parameter's packed set is found again while tensor, version counter and pointer are the
-    same, and rebuilt after an in-place update (what an optimizer step or load_state_dict does)."""
+    """train_hip.fixed_weights / PackStore: a parameter's packed set is found again while its memory and version counter
+    are the same, refilled after an in-place update (what an optimizer step or load_state_dict does) - on demand, or
+    for every stale set at once when a block is entered - and bit-equal to a set packed on its own; a folded per-channel
+    scale is part of the key and of the staleness check."""
     from video_diffusion_amd import train_hip as T
     w = torch.nn.Parameter(torch.randn(64, 64, 1, 3, 3, device=DEV))
-    store = {}
+    w1 = torch.nn.Parameter(torch.randn(192, 64, device=DEV))
+    gam = torch.nn.Parameter(1 + 0.3 * torch.randn(1, 64, 1, 1, 1, device=DEV))
+    store = T.PackStore()
+    lin = lambda tr: T._linear_pack(w1.detach(), tr, gam)
     with T.fixed_weights(store):
         p0 = T.param_pack(w, False)
         assert T.param_pack(w, False) is p0 and T.param_pack(w, True) is not p0 and len(store) == 2
+        d0 = p0.data.clone()
         with torch.no_grad():
             w.mul_(2.0)
         p1 = T.param_pack(w, False)
-        assert p1 is not p0
-        assert torch.equal(p1.data.float(), (p0.data.float() * 2.0))
+        assert p1 is p0 and torch.equal(p1.data.float(), d0.float() * 2.0)            # refilled in place
+        l0, l1 = lin(False), lin(True)
+        folded = (w1.detach() * gam.detach().reshape(1, 64)).contiguous()
+        for tr, got in ((False, l0), (True, l1)):
+            assert torch.equal(got.data, T.DevPack(folded.reshape(192, 64, 1, 1, 1), tr).data)
+        assert len(store) == 4
     assert T._PACKS is None
     assert T.param_pack(w, False) is not p1                 # outside a block nothing is kept
+    # the batched refill at the next block: every set is stale after "an optimizer step"
+    with torch.no_grad():
+        w.add_(0.5)
+        w1.mul_(-1.0)
+        gam.add_(0.1)
+    with T.fixed_weights(store):
+        assert not any(store._stale(e) for e in store.entries.values())
+        folded = (w1.detach() * gam.detach().reshape(1, 64)).contiguous()
+        assert torch.equal(T.param_pack(w, False).data, T.DevPack(w, False).data)
+        assert torch.equal(T.param_pack(w, True).data, T.DevPack(w, True).data)
+        assert torch.equal(lin(False).data, T.DevPack(folded.reshape(192, 64, 1, 1, 1), False).data)
+        assert torch.equal(lin(True).data, T.DevPack(folded.reshape(192, 64, 1, 1, 1), True).data)
+    # writes through .data do not move the version counter: invalidate() is the caller's tool for those
+    w.data.mul_(3.0)
+    with T.fixed_weights(store):
+        assert not torch.equal(T.param_pack(w, False).data, T.DevPack(w, False).data)
+    store.invalidate()
+    with T.fixed_weights(store):
+        assert torch.equal(T.param_pack(w, False).data, T.DevPack(w, False).data)
+    # sets nobody asks for are dropped after two refreshes
+    for _ in range(3):
+        with T.fixed_weights(store):
+            T.param_pack(w, False)
+    assert len(store) == 1
 
 
 def test_long_frame_axis_falls_back_to_torch_ops_under_the_hip_backend():

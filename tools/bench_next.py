@@ -131,16 +131,23 @@ def train_step(args, dev):
     # --train-context L: previous-frame conditioning features (B, L, 512), i.e. the eight CrossAttention layers in the step
     feats = torch.randn(B, args.train_context, 512, device=dev, requires_grad=True) if args.train_context else None
 
+    from video_diffusion_amd import train_hip
+    store = train_hip.PackStore()
+
     def step(backend, amp):
         unet.train_backend = backend
         for p in unet.parameters():
             p.grad = None
         if feats is not None:
             feats.grad = None
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            eps = unet(x, t) if feats is None else unet(x, t, frame_cond_features=feats)
-            loss = F.l1_loss(eps.float(), noise)
-        loss.backward()
+        # as in the Trainer: the packed weight sets live in a store; every step counts as following an optimizer step
+        # (all sets stale), so each step packs every weight once, in the store's one batched launch
+        store.invalidate()
+        with train_hip.fixed_weights(store):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                eps = unet(x, t) if feats is None else unet(x, t, frame_cond_features=feats)
+                loss = F.l1_loss(eps.float(), noise)
+            loss.backward()
         return loss
 
     out = {"workload": f"training step: Unet3D(dim={args.train_dim}, channels={args.train_channels}) p_losses forward + backward on {tuple(x.shape)}, "

@@ -75,6 +75,13 @@ class DdpmCoefs(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    """include/vdmi.h: vdmi_pack_job"""
+    _fields_ = [("w", C.c_void_p), ("in_scale", C.c_void_p), ("out", C.c_void_p),
+                ("n", C.c_int), ("npad", C.c_int), ("cin0", C.c_int), ("cin1", C.c_int), ("ntaps", C.c_int),
+                ("bkc", C.c_int), ("transposed", C.c_int)]
+
+
 class VdmiError(RuntimeError):
     pass
 
@@ -162,6 +169,8 @@ _SIGNATURES = {
     "vdmi_ddpm_step_thres": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DdpmCoefs), C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "vdmi_pack_taps_device": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
+    "vdmi_pack_taps_batch_table_bytes": (C.c_size_t, [C.c_int]),
+    "vdmi_pack_taps_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vdmi_rows_transpose_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int64]),
     "vdmi_rows_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "vdmi_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 6),

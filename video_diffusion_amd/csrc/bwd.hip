@@ -18,16 +18,18 @@
 //   The RMSNorm / scale-shift / SiLU backward is a row kernel (two row reductions, per-channel sums by atomics).
 #include "vdmi_common.h"
 
+#include <vector>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------------------------
 // weight packing on the device: the layout of vdmi_pack_taps (host_utils.cpp), one 16-byte piece per thread
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_taps_kernel(const float* __restrict__ w, int n, int npad, int cin0, int cin1,
-                                                        int ntaps, int bkc, int transposed, __bf16* __restrict__ out,
-                                                        long long pieces) {
-    const long long o8 = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (o8 >= pieces) return;
+// `in_scale` (float [cin0 + cin1] of the FORWARD weight's input channels, or null) multiplies every element by the
+// factor of its input channel: a LayerNorm gamma folded into the projection that follows it
+__device__ __forceinline__ void pack_taps_piece(const float* __restrict__ w, const float* __restrict__ in_scale, int n, int npad,
+                                                int cin0, int cin1, int ntaps, int bkc, int transposed,
+                                                __bf16* __restrict__ out, long long o8) {
     const int ks_per = bkc / 16, nct = npad / 32, nch0 = (cin0 + bkc - 1) / bkc;
     const int lane = (int)(o8 & 63);
     long long r = o8 >> 6;
@@ -47,12 +49,44 @@ __global__ __launch_bounds__(256) void pack_taps_kernel(const float* __restrict_
         float f = 0.f;
         if (co < n && ci < clim) {
             // transposed: `w` is the forward convolution's weight [cin][n][ntaps] seen from its output side, taps reversed
+            // (this pass's output channel co is the forward weight's input channel)
             f = transposed ? w[((size_t)(coff + ci) * n + co) * ntaps + (ntaps - 1 - t)]
                            : w[((size_t)co * cin + coff + ci) * ntaps + t];
+            if (in_scale) f *= transposed ? in_scale[co] : in_scale[coff + ci];
         }
         v[j] = f2bf(f);
     }
     *reinterpret_cast<bf16x8*>(out + o8 * 8) = v;
+}
+
+__global__ __launch_bounds__(256) void pack_taps_kernel(const float* __restrict__ w, int n, int npad, int cin0, int cin1,
+                                                        int ntaps, int bkc, int transposed, __bf16* __restrict__ out,
+                                                        long long pieces) {
+    const long long o8 = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o8 >= pieces) return;
+    pack_taps_piece(w, nullptr, n, npad, cin0, cin1, ntaps, bkc, transposed, out, o8);
+}
+
+// many weight sets in one launch: the job table (device copy of vdmi_pack_job records) is sorted by first workgroup
+struct PackJobDev {
+    const float* w;
+    const float* in_scale;
+    __bf16* out;
+    long long pieces, block_begin;
+    int n, npad, cin0, cin1, ntaps, bkc, transposed, pad_;
+};
+static_assert(sizeof(PackJobDev) == 72, "job record");
+
+__global__ __launch_bounds__(256) void pack_taps_batch_kernel(const PackJobDev* __restrict__ jobs, int count) {
+    int lo = 0, hi = count - 1;                 // the last job whose first workgroup is <= this one
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJobDev j = jobs[lo];
+    const long long o8 = ((long long)blockIdx.x - j.block_begin) * 256 + threadIdx.x;
+    if (o8 >= j.pieces) return;
+    pack_taps_piece(j.w, j.in_scale, j.n, j.npad, j.cin0, j.cin1, j.ntaps, j.bkc, j.transposed, j.out, o8);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -350,7 +384,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int co = bx * 64 + rl, ci = by * 64 + cl;
     if (co >= cout || ci >= cin) return;
     float sum = 0.f;
-    for (int z = 0; z < nz; ++z) sum += part[(size_t)z * per_z + e];
+#pragma unroll 8
+    for (int z = 0; z < nz; ++z) sum += part[(size_t)z * per_z + e];      // eight loads in flight, added in order
     dw[((size_t)co * cin_total + cin_off + ci) * nt + t] = sum;
 }
 
@@ -668,6 +703,41 @@ extern "C" int vdmi_pack_taps_device(const float* w, int n, int npad, int cin0, 
     if (blocks > 0x7fffffffLL) return VDMI_E_SHAPE;
     hipLaunchKernelGGL(pack_taps_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, n,
                        npad, cin0, cin1, ntaps, bkc, transposed ? 1 : 0, static_cast<__bf16*>(out), pieces);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+extern "C" size_t vdmi_pack_taps_batch_table_bytes(int count) { return count > 0 ? (size_t)count * sizeof(PackJobDev) : 0; }
+
+extern "C" int vdmi_pack_taps_batch(const vdmi_pack_job* jobs, int count, void* device_table, vdmi_stream stream) {
+    if (!jobs || !device_table || count <= 0) return VDMI_E_ARG;
+    if (count > 65536) return VDMI_E_SHAPE;
+    std::vector<PackJobDev> tab((size_t)count);
+    long long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const vdmi_pack_job& j = jobs[i];
+        if (!j.w || !j.out) return VDMI_E_ARG;
+        if (j.n <= 0 || j.npad < j.n || j.npad % 32 || j.cin0 <= 0 || j.cin1 < 0 || j.ntaps <= 0 || (j.bkc != 32 && j.bkc != 64))
+            return VDMI_E_SHAPE;
+        if (!aligned16(j.out)) return VDMI_E_ALIGN;
+        PackJobDev& d = tab[(size_t)i];
+        d.w = j.w;
+        d.in_scale = j.in_scale;
+        d.out = static_cast<__bf16*>(j.out);
+        d.pieces = (long long)vdmi_pack_taps_elems(j.n, j.npad, j.cin0, j.cin1, j.ntaps, j.bkc) / 8;
+        d.block_begin = blocks;
+        d.n = j.n; d.npad = j.npad; d.cin0 = j.cin0; d.cin1 = j.cin1; d.ntaps = j.ntaps; d.bkc = j.bkc;
+        d.transposed = j.transposed ? 1 : 0;
+        d.pad_ = 0;
+        blocks += (d.pieces + 255) / 256;
+    }
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return VDMI_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // pageable source: the runtime stages the bytes before the call returns, so `tab` may go out of scope
+    if (hipMemcpyAsync(device_table, tab.data(), tab.size() * sizeof(PackJobDev), hipMemcpyHostToDevice, st) != hipSuccess)
+        return VDMI_E_LAUNCH;
+    hipLaunchKernelGGL(pack_taps_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                       static_cast<const PackJobDev*>(device_table), count);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }

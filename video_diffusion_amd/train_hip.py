@@ -74,12 +74,13 @@ def torch_ops(fn, *xs):
 class DevPack:
     """A weight set in the tap-GEMM's fragment order, packed on the device (weights change every optimizer step)."""
 
-    def __init__(self, weight: torch.Tensor, transposed: bool, tile_bn=None):
+    def __init__(self, weight: torch.Tensor, transposed: bool, tile_bn=None, in_scale=None, fill=True):
         # weight: a Conv3d weight (cout, cin, 1, kh, kw), or the same as [cout][cin][taps].  transposed: the set of the
-        # input-gradient pass.  tile_bn: 64 forces 64-channel output tiles, 0 the automatic tile, None picks by width
+        # input-gradient pass.  tile_bn: 64 forces 64-channel output tiles, 0 the automatic tile, None picks by width.
+        # in_scale: float [cin] factors of the weight's input channels, multiplied in while packing (a folded gamma)
         cout, cin = weight.shape[0], weight.shape[1]
         ntaps = weight[0, 0].numel()
-        w3 = weight.detach().reshape(cout, cin, ntaps).to(torch.float32).contiguous()
+        self.transposed = bool(transposed)
         self.n, self.k = (cin, cout) if transposed else (cout, cin)
         self.ntaps = ntaps
         self.tile_bn = (64 if (self.n >= 256 and self.n % 64 == 0) else 0) if tile_bn is None else tile_bn
@@ -90,29 +91,119 @@ class DevPack:
             check(_lib.lib().vdmi_tapgemm_tile(EPI_PLAIN, self.n, C.byref(bn), C.byref(bkc)), "vdmi_tapgemm_tile")
             self.bn, self.bkc = bn.value, bkc.value
         self.npad = (self.n + self.bn - 1) // self.bn * self.bn
-        lib = _lib.lib()
-        elems = lib.vdmi_pack_taps_elems(self.n, self.npad, self.k, 0, ntaps, self.bkc)
+        elems = _lib.lib().vdmi_pack_taps_elems(self.n, self.npad, self.k, 0, ntaps, self.bkc)
         self.data = torch.empty(elems, dtype=torch.bfloat16, device=weight.device)
-        check(lib.vdmi_pack_taps_device(w3.data_ptr(), self.n, self.npad, self.k, 0, ntaps, self.bkc,
-                                        1 if transposed else 0, self.data.data_ptr(), _stream()), "vdmi_pack_taps_device")
-        self._keep = w3
+        self._keep = None
+        if fill:
+            self.fill(weight, in_scale)
+
+    def job(self, weight: torch.Tensor, in_scale=None) -> "_lib.PackJob":
+        """The vdmi_pack_job that fills this set from `weight`; the float32 tensors it reads stay referenced by the set."""
+        w3 = weight.detach().reshape(weight.shape[0], weight.shape[1], self.ntaps).to(torch.float32).contiguous()
+        sc = None if in_scale is None else in_scale.detach().reshape(-1).to(torch.float32).contiguous()
+        assert sc is None or sc.numel() == weight.shape[1]
+        self._keep = (w3, sc)
+        return _lib.PackJob(w3.data_ptr(), None if sc is None else sc.data_ptr(), self.data.data_ptr(), self.n, self.npad,
+                            self.k, 0, self.ntaps, self.bkc, 1 if self.transposed else 0)
+
+    def fill(self, weight: torch.Tensor, in_scale=None):
+        lib = _lib.lib()
+        if in_scale is None:
+            j = self.job(weight)
+            check(lib.vdmi_pack_taps_device(j.w, j.n, j.npad, j.cin0, j.cin1, j.ntaps, j.bkc, j.transposed, j.out, _stream()),
+                  "vdmi_pack_taps_device")
+        else:
+            pack_batch([self.job(weight, in_scale)], weight.device)
 
 
-_PACKS = None        # {(id, version, pointer, transposed): DevPack} while a caller has declared the weights fixed
+def pack_batch(jobs, device):
+    """All of `jobs` (a list of _lib.PackJob) in one launch."""
+    lib = _lib.lib()
+    arr = (_lib.PackJob * len(jobs))(*jobs)
+    table = torch.empty(lib.vdmi_pack_taps_batch_table_bytes(len(jobs)), device=device, dtype=torch.uint8)
+    check(lib.vdmi_pack_taps_batch(C.cast(arr, C.c_void_p), len(jobs), table.data_ptr(), _stream()), "vdmi_pack_taps_batch")
+    return table
+
+
+class PackStore:
+    """Packed weight sets that outlive a forward / backward, for a caller that knows when the weights change (the Trainer
+    around its optimizer step, a sampler whose weights are frozen).  A set is found again by the weight's memory and
+    shape and trusted while the version counters of the weight (and of its scale) stand where they stood when it was
+    packed.  In-place updates under no_grad (load_state_dict, the single-tensor and foreach optimizers) move them; a
+    FUSED optimizer step (torch._fused_adam_) and writes through `.data` do not - whoever runs those calls invalidate()
+    afterwards, as the Trainer does after every optimizer step.  refresh() repacks every set that went stale in ONE
+    launch (a training step otherwise spends ~200 launches of a few microseconds of work each on it)."""
+
+    class _Entry:
+        __slots__ = ("pack", "weight", "scale", "wv", "sv", "age")
+
+    def __init__(self):
+        self.entries = {}
+        self._table = None
+
+    def __len__(self):
+        return len(self.entries)
+
+    def invalidate(self):
+        for e in self.entries.values():
+            e.wv = -1
+
+    @staticmethod
+    def _stale(e):
+        return e.wv != e.weight._version or (e.scale is not None and e.sv != e.scale._version)
+
+    @staticmethod
+    def _stamp(e):
+        e.wv = e.weight._version
+        e.sv = None if e.scale is None else e.scale._version
+
+    def get(self, weight: torch.Tensor, transposed: bool, tile_bn=None, in_scale=None) -> DevPack:
+        key = (weight.data_ptr(), tuple(weight.shape), bool(transposed), tile_bn,
+               None if in_scale is None else in_scale.data_ptr())
+        e = self.entries.get(key)
+        if e is None:
+            e = PackStore._Entry()
+            e.pack = DevPack(weight, transposed, tile_bn, fill=False)
+            # aliases of the caller's tensors: they share the version counters and keep the memory (and with it the key) theirs
+            e.weight, e.scale = weight.detach(), None if in_scale is None else in_scale.detach()
+            e.wv = -1
+            self.entries[key] = e
+        e.age = 0
+        if self._stale(e):
+            e.pack.fill(e.weight, e.scale)
+            self._stamp(e)
+        return e.pack
+
+    def refresh(self):
+        """Repack every stale set in one launch; sets no caller asked for since the refresh before the last are dropped."""
+        for k in [k for k, e in self.entries.items() if e.age >= 2]:
+            del self.entries[k]
+        stale = [e for e in self.entries.values() if self._stale(e)]
+        for e in self.entries.values():
+            e.age += 1
+        if not stale:
+            return
+        self._table = pack_batch([e.pack.job(e.weight, e.scale) for e in stale], stale[0].weight.device)
+        for e in stale:
+            self._stamp(e)
+
+
+_PACKS = None        # the PackStore of the enclosing fixed_weights block
 
 
 class fixed_weights:
-    """`with fixed_weights(store):` - the caller guarantees that the parameters keep their values between the forwards and
-    backwards run inside this and later blocks with the same `store` (a dict it owns): the packed weight sets of the
-    ResnetBlocks are then built once and found again by (tensor, version counter, pointer).  The guided sampler uses it
-    (weights are frozen while it samples); training does not - an optimizer step changes every weight anyway."""
+    """`with fixed_weights(store):` - the caller guarantees that the parameters change only through version-counted in-place
+    updates between the forwards and backwards run inside this and later blocks with the same `store` (a PackStore it
+    owns): the packed weight sets of the HIP layers are then kept in the store, and entering the block repacks the stale
+    ones in one launch.  The Trainer wraps its micro-steps in it, the guided sampler its loop (weights frozen)."""
 
-    def __init__(self, store: dict):
+    def __init__(self, store: PackStore):
         self.store = store
 
     def __enter__(self):
         global _PACKS
         self.prev, _PACKS = _PACKS, self.store
+        self.store.refresh()
         return self
 
     def __exit__(self, *exc):
@@ -121,17 +212,11 @@ class fixed_weights:
         return False
 
 
-def param_pack(weight: torch.Tensor, transposed: bool) -> DevPack:
+def param_pack(weight: torch.Tensor, transposed: bool, tile_bn=None, in_scale=None) -> DevPack:
     """DevPack of a parameter, through the store of an enclosing fixed_weights block when there is one."""
     if _PACKS is None:
-        return DevPack(weight, transposed)
-    key = (id(weight), weight._version, weight.data_ptr(), transposed)
-    hit = _PACKS.get(key)
-    if hit is None or hit[0]() is not weight:
-        import weakref
-        hit = (weakref.ref(weight), DevPack(weight, transposed))
-        _PACKS[key] = hit
-    return hit[1]
+        return DevPack(weight, transposed, tile_bn, in_scale)
+    return _PACKS.get(weight, transposed, tile_bn, in_scale)
 
 
 def conv_rows(src: torch.Tensor, pack: DevPack, bias, frames: int, fpb: int, h: int, w: int, residual=None) -> torch.Tensor:
@@ -544,9 +629,9 @@ def _supports(unet, ok) -> bool:
 # ---------------------------------------------------------------------------------------------------------------------
 # temporal attention layer: Residual(PreNorm(EinopsToAndFrom('b c f h w', 'b (h w) f c', Attention)))
 # ---------------------------------------------------------------------------------------------------------------------
-def _linear_pack(w2: torch.Tensor, transposed: bool) -> DevPack:
-    """A Linear weight [n][k] as a one-tap weight set."""
-    return DevPack(w2.reshape(w2.shape[0], w2.shape[1], 1, 1, 1), transposed)
+def _linear_pack(w2: torch.Tensor, transposed: bool, in_scale=None) -> DevPack:
+    """A Linear weight [n][k] (or a 1x1x1 convolution's) as a one-tap weight set; in_scale: factors of its k input channels."""
+    return param_pack(w2.reshape(w2.shape[0], w2.shape[1], 1, 1, 1), transposed, None, in_scale)
 
 
 class TemporalAttnFn(torch.autograd.Function):
@@ -566,8 +651,8 @@ class TemporalAttnFn(torch.autograd.Function):
         xr = to_rows(x)
         xh = torch.empty_like(xr)
         check(lib.vdmi_layernorm_rows(xr.data_ptr(), xh.data_ptr(), rows, c, eps, _stream()), "vdmi_layernorm_rows")
-        wp = (wqkv.detach() * gamma.detach().reshape(1, c)).contiguous()            # LayerNorm gamma folded into to_qkv
-        qkv = conv_rows(xh, _linear_pack(wp, False), None, b * f, f, h, w)
+        # LayerNorm gamma folded into to_qkv while its weight set is packed
+        qkv = conv_rows(xh, _linear_pack(wqkv.detach(), False, gamma), None, b * f, f, h, w)
         o = torch.empty(rows, hid, device=x.device, dtype=torch.bfloat16)
         lse = torch.empty(rows, heads, device=x.device, dtype=torch.float32)
         bias_c = None if bias is None else bias.detach().float().contiguous()
@@ -579,7 +664,7 @@ class TemporalAttnFn(torch.autograd.Function):
         check(lib.vdmi_tattn_core_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ptr(bias_c), ptr(cos), ptr(sin), ptr(foc),
                                       *core, heads, scale, _stream()), "vdmi_tattn_core_fwd")
         y = conv_rows(o, _linear_pack(wout.detach().contiguous(), False), None, b * f, f, h, w, residual=xr)
-        ctx.save_for_backward(xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin, foc)
+        ctx.save_for_backward(xr, xh, qkv, o, lse, wqkv, wout, gamma, bias_c, cos, sin, foc)
         ctx.meta = (b, c, f, h, w, heads, scale, eps, core)
         ctx.act = _act_dtype(x)
         return from_rows(y, b, f, h, w, ctx.act)
@@ -587,7 +672,7 @@ class TemporalAttnFn(torch.autograd.Function):
     @staticmethod
     @_plain
     def backward(ctx, dy):
-        xr, xh, qkv, o, lse, wp, wqkv, wout, gamma, bias_c, cos, sin, foc = ctx.saved_tensors
+        xr, xh, qkv, o, lse, wqkv, wout, gamma, bias_c, cos, sin, foc = ctx.saved_tensors
         b, c, f, h, w, heads, scale, eps, core = ctx.meta
         lib = _lib.lib()
         hw, rows, hid, frames = h * w, b * f * h * w, heads * 32, b * f
@@ -608,7 +693,7 @@ class TemporalAttnFn(torch.autograd.Function):
                                       ptr(dbias), ptr(bias_c), ptr(cos), ptr(sin), ptr(foc), *core, heads, scale, ptr(ws),
                                       _stream()), "vdmi_tattn_core_bwd")
         # to_qkv (with the folded gamma), LayerNorm, residual
-        dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
+        dxh = conv_rows(dqkv, _linear_pack(wqkv.detach(), True, gamma), None, frames, f, h, w)
         dwqkv = dgamma = None
         if need[1] or need[2]:
             dwp = rows_wgrad(xh, dqkv)
@@ -1016,9 +1101,8 @@ class SlaFn(torch.autograd.Function):
         xr = to_rows(x)
         xh = torch.empty_like(xr)
         check(lib.vdmi_layernorm_rows(xr.data_ptr(), xh.data_ptr(), rows, c, eps, _stream()), "vdmi_layernorm_rows")
-        wq2, wo2 = wqkv.detach().reshape(3 * hid, c), wout.detach().reshape(c, hid)
-        wp = (wq2 * gamma.detach().reshape(1, c)).contiguous()
-        qkv = conv_rows(xh, _linear_pack(wp, False), None, frames, f, h, w)
+        wo2 = wout.detach().reshape(c, hid)
+        qkv = conv_rows(xh, _linear_pack(wqkv.detach(), False, gamma), None, frames, f, h, w)   # gamma folded while packing
         base = qkv.data_ptr()
         p_ctx = _sla_reduce(base + 2 * hid, 3 * hid, base + 4 * hid, 3 * hid, None, frames, n, heads, 0, x.device)
         out = torch.empty(rows, hid, device=x.device, dtype=torch.bfloat16)
@@ -1027,7 +1111,7 @@ class SlaFn(torch.autograd.Function):
                                           scale, _stream()), "vdmi_sla_train_rows_fwd")
         y = conv_rows(out, _linear_pack(wo2.contiguous(), False), bout.detach().float().contiguous(), frames, f, h, w,
                       residual=xr)
-        ctx.save_for_backward(xr, xh, qkv, qt, out, p_ctx, wp, wqkv, wout, gamma)
+        ctx.save_for_backward(xr, xh, qkv, qt, out, p_ctx, wqkv, wout, gamma)
         ctx.meta = (b, c, f, h, w, heads, scale, eps)
         ctx.act = _act_dtype(x)
         return from_rows(y, b, f, h, w, ctx.act)
@@ -1035,7 +1119,7 @@ class SlaFn(torch.autograd.Function):
     @staticmethod
     @_plain
     def backward(ctx, dy):
-        xr, xh, qkv, qt, out, p_ctx, wp, wqkv, wout, gamma = ctx.saved_tensors
+        xr, xh, qkv, qt, out, p_ctx, wqkv, wout, gamma = ctx.saved_tensors
         b, c, f, h, w, heads, scale, eps = ctx.meta
         lib = _lib.lib()
         n, frames, hid = h * w, b * f, heads * 32
@@ -1051,7 +1135,7 @@ class SlaFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         check(lib.vdmi_sla_train_rows_bwd(qkv.data_ptr(), qt.data_ptr(), do.data_ptr(), p_ctx.data_ptr(), p_dctx.data_ptr(),
                                           dqkv.data_ptr(), frames, n, heads, scale, _stream()), "vdmi_sla_train_rows_bwd")
-        dxh = conv_rows(dqkv, _linear_pack(wp, True), None, frames, f, h, w)
+        dxh = conv_rows(dqkv, _linear_pack(wqkv.detach(), True, gamma), None, frames, f, h, w)
         dwqkv = dgamma = None
         if need[1] or need[2]:
             dwp = rows_wgrad(xh, dqkv)

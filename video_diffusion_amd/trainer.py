@@ -324,13 +324,21 @@ class Trainer(object):
             # that does receive a gradient raises).
             loss_mod = nn.parallel.DistributedDataParallel(loss_core, find_unused_parameters=True, **ddp_kw)
 
+        # packed weight sets of the HIP layers: kept over the micro-steps of an accumulation, repacked (one launch) after
+        # the optimizer step has moved the parameters' version counters
+        packs, store = _nullcontext, None
+        if getattr(self.model.denoise_fn, "train_backend", None) in ("hip", "hip-resnet"):
+            from . import train_hip
+            store = train_hip.PackStore()
+            packs = lambda: train_hip.fixed_weights(store)
+
         while self.step < self.train_num_steps:
             for i in range(self.gradient_accumulate_every):
                 batch = next(self.dl)
                 current_frames, prev_frames = batch['current'].to(dev), batch['prev'].to(dev)
                 last = i == self.gradient_accumulate_every - 1
                 sync = loss_mod.no_sync if (self.distributed and not last) else _nullcontext
-                with sync():
+                with sync(), packs():
                     with torch.autocast(dev.type, enabled=self.amp):
                         total_loss, diffusion_loss, vae_loss = loss_mod(current_frames, prev_frames, prob_focus_present,
                                                                         focus_present_mask)
@@ -356,6 +364,8 @@ class Trainer(object):
                 if self.model.frame_cond_encoder is not None:
                     nn.utils.clip_grad_norm_(self.model.frame_cond_encoder.parameters(), self.max_grad_norm)
             self.scaler.step(self.opt)
+            if store is not None:
+                store.invalidate()      # a fused optimizer step leaves the parameters' version counters where they were
             if self.step % 20 == 0 and self.rank == 0:
                 print(f'{self.step}: diff_loss={log["loss"]:.4f}, vae_loss={log["vae_loss"]:.4f}')
             self.scaler.update()

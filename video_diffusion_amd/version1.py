@@ -163,7 +163,8 @@ def temporal_consistency_guidance(model, prev_frames, overlap_frames, w_r=1.0):
     for param in model.vae.decoder.parameters():
         param.requires_grad = False
 
-    packs = {}       # packed weight sets of the HIP training layers, kept over the steps of the loop (weights are frozen)
+    from . import train_hip as _th0
+    packs = _th0.PackStore()    # packed weight sets of the HIP training layers, kept over the steps of the loop (weights are frozen)
 
     def guidance_fn(z_t, t):
         if prev_frames is None:
