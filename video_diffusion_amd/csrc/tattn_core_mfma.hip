@@ -70,6 +70,9 @@ template <bool BWD>
 __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const McArgs a) {
     // per wave: transposition images (fwd: V; bwd: K, Q, dO) and, bwd, log-sum-exp and delta by token
     __shared__ __attribute__((aligned(16))) char img[MC_WAVES][BWD ? 3 : 1][32 * 64];
+    // results on their way out: [token][80 B] (64 B of a head's features + padding), written as the accumulators hold them
+    // (lane = token, 4 features per piece) and read back as 16-byte pieces, four lanes to a row
+    __shared__ __attribute__((aligned(16))) char oimg[MC_WAVES][32 * 80];
     __shared__ __attribute__((aligned(16))) float stats[BWD ? MC_WAVES : 1][2][32];
     // bwd: the bias in both orientations, [orientation][register / 4][lane] float4 (registers go to the next unit's rows)
     __shared__ __attribute__((aligned(16))) f32x4 btab[BWD ? MC_WAVES : 1][2][4][64];
@@ -122,6 +125,14 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
     const int g16 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
     const int tr_off = (8 * (g16 >> 1) + tq) * 64 + (16 * (g16 & 1) + 4 * tp) * 2;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // the tokens whose rows this lane writes: 16 j + lane / 4, piece lane % 4
+    int oslot[2], ofi[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tok = 16 * j + (lane >> 2);
+        oslot[j] = tok / F;
+        ofi[j] = tok - oslot[j] * F;
+    }
 
     auto rotate = [&](bf16x8& x0, bf16x8& x1, float mul) {
 #pragma unroll
@@ -135,20 +146,33 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
         *reinterpret_cast<bf16x8*>(im + wr_off) = x0;
         *reinterpret_cast<bf16x8*>(im + wr_off + 32) = x1;
     };
-    // gradient of a rotated row in accumulator layout -> gradient of the raw row, times mul; 8-byte stores
-    auto store_unrotated = [&](f32x16 x, float mul, __bf16* dst) {
+    // gradient of a rotated row in accumulator layout -> gradient of the raw row, times mul
+    auto unrotate = [&](f32x16& x, float mul) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float lo = x[r], hi = x[r + 8];
             x[r] = (lo * rc2[r] + hi * rs2[r]) * mul;
             x[r + 8] = (hi * rc2[r] - lo * rs2[r]) * mul;
         }
+    };
+    // x (lane = token, register r = feature acc_row(r, half)) -> 64-byte row segments at dst + row * ldd, through LDS
+    auto store_rows = [&](const f32x16& x, long long tile, __bf16* dst, int ldd) {
+        char* im = oimg[wave];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             bf16x4 o4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o4[e] = f2bf(x[4 * rg + e]);
-            *reinterpret_cast<bf16x4*>(dst + 8 * rg) = o4;
+            *reinterpret_cast<bf16x4*>(im + l31 * 80 + 16 * rg + 8 * half) = o4;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(im + (16 * j + (lane >> 2)) * 80 + 16 * (lane & 3));
+            const long long site = tile * a.g + oslot[j];
+            if (oslot[j] < a.g && site < a.nsites) {
+                const long long bb = site / a.hw, sp = site - bb * a.hw;
+                *reinterpret_cast<bf16x8*>(dst + ((bb * F + ofi[j]) * a.hw + sp) * ldd + 8 * (lane & 3)) = v;
+            }
         }
     };
 
@@ -169,7 +193,29 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
         n.foc = a.focus && n.ok && a.focus[bb] != 0;
         n.q0 = n.q1 = n.k0 = n.k1 = n.v0 = n.v1 = zero8;
         if constexpr (BWD) { n.g0 = n.g1 = n.o0 = n.o1 = zero8; n.lse = 0.f; }
+#ifdef VDMI_MC_ABL_NOLOAD       // timing-only ablation (wrong results): no row is read
+        if (n.ok && a.scale < -1.f) {
+#else
         if (n.ok) {
+#endif
+#ifdef VDMI_MC_ABL_COALESCED    // timing-only ablation (wrong results): four lanes read the 64 contiguous bytes of a row
+            long long rj[2];
+            for (int j = 0; j < 2; ++j) {
+                const int tok = 16 * j + (lane >> 2), sl = tok / F, fr = tok - sl * F;
+                long long st2 = tile * a.g + sl;
+                if (st2 >= a.nsites) st2 = a.nsites - 1;
+                const long long b2 = st2 / a.hw, s2 = st2 - b2 * a.hw;
+                rj[j] = (b2 * F + fr) * a.hw + s2;
+            }
+            const __bf16* p0 = a.qkv + rj[0] * ld + head * 32 + 8 * (lane & 3);
+            const __bf16* p1 = a.qkv + rj[1] * ld + head * 32 + 8 * (lane & 3);
+            n.q0 = *reinterpret_cast<const bf16x8*>(p0);
+            n.q1 = *reinterpret_cast<const bf16x8*>(p1);
+            n.k0 = *reinterpret_cast<const bf16x8*>(p0 + ldo);
+            n.k1 = *reinterpret_cast<const bf16x8*>(p1 + ldo);
+            n.v0 = *reinterpret_cast<const bf16x8*>(p0 + 2 * ldo);
+            n.v1 = *reinterpret_cast<const bf16x8*>(p1 + 2 * ldo);
+#else
             const __bf16* p = a.qkv + n.row * ld + head * 32 + 8 * half;
             n.q0 = *reinterpret_cast<const bf16x8*>(p);
             n.q1 = *reinterpret_cast<const bf16x8*>(p + 16);
@@ -177,6 +223,7 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
             n.k1 = *reinterpret_cast<const bf16x8*>(p + ldo + 16);
             n.v0 = *reinterpret_cast<const bf16x8*>(p + 2 * ldo);
             n.v1 = *reinterpret_cast<const bf16x8*>(p + 2 * ldo + 16);
+#endif
             if constexpr (BWD) {
                 const __bf16* gp = a.dout + n.row * ldo + head * 32 + 8 * half;
                 const __bf16* op = a.o + n.row * ldo + head * 32 + 8 * half;
@@ -194,7 +241,11 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
     for (long long u = wave_gid; u < a.units; u += stride) {
         const Unit c = nx;
         fetch(u + stride, nx);
+#ifdef VDMI_MC_ABL_NOSTORE      // timing-only ablation: nothing is written
+        const bool ok = c.ok && a.scale < -1.f, foc = c.foc;
+#else
         const bool ok = c.ok, foc = c.foc;
+#endif
         const long long row = c.row;
         const unsigned mask = ok ? (foc ? mask_self : mask_same) : 0u;
         bf16x8 q0 = c.q0, q1 = c.q1, k0 = c.k0, k1 = c.k1;
@@ -226,18 +277,11 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt0, acc_frag(st, 0), o, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt1, acc_frag(st, 1), o, 0, 0, 0);
-            if (ok) {
-                const float inv = 1.0f / l;
-                __bf16* dst = a.out + row * ldo + head * 32 + 4 * half;
+            const float inv = 1.0f / l;
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    bf16x4 o4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = f2bf(o[4 * rg + e] * inv);
-                    *reinterpret_cast<bf16x4*>(dst + 8 * rg) = o4;
-                }
-                if (half == 0) a.lse_out[row * H + head] = (m + __builtin_amdgcn_logf(l)) * LN2;
-            }
+            for (int r = 0; r < 16; ++r) o[r] *= inv;
+            store_rows(o, u / H, a.out + head * 32, ldo);
+            if (ok && half == 0) a.lse_out[row * H + head] = (m + __builtin_amdgcn_logf(l)) * LN2;
         } else {
             const bf16x8 g0 = c.g0, g1 = c.g1;
             float delta = 0.f;
@@ -279,7 +323,8 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
                 for (int r = 0; r < 16; ++r) dq[r] = 0.f;
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0, acc_frag(st, 0), dq, 0, 0, 0);
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt1, acc_frag(st, 1), dq, 0, 0, 0);
-                if (ok) store_unrotated(dq, a.scale, a.out + row * ld + head * 32 + 4 * half);
+                unrotate(dq, a.scale);
+                store_rows(dq, u / H, a.out + head * 32, ld);
             }
             // ---- lane = key:  P, dS = P (dP - delta), dv^T = dO^T P, dk^T = Q^T dS
             {
@@ -313,17 +358,9 @@ __global__ __launch_bounds__(MC_WAVES * 64) void tattn_core_mfma_kernel(const Mc
                 dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0, acc_frag(dp, 0), dk, 0, 0, 0);
                 dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt1, acc_frag(s, 1), dv, 0, 0, 0);
                 dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1, acc_frag(dp, 1), dk, 0, 0, 0);
-                if (ok) {
-                    store_unrotated(dk, LN2, a.out + row * ld + (H + head) * 32 + 4 * half);
-                    __bf16* dst = a.out + row * ld + (2 * H + head) * 32 + 4 * half;
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        bf16x4 o4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = f2bf(dv[4 * rg + e]);
-                        *reinterpret_cast<bf16x4*>(dst + 8 * rg) = o4;
-                    }
-                }
+                unrotate(dk, LN2);
+                store_rows(dk, u / H, a.out + (H + head) * 32, ld);
+                store_rows(dv, u / H, a.out + (2 * H + head) * 32, ld);
             }
         }
     }
