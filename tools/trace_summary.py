@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1, help="steps the traced run made (totals are divided by it)")
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--match", default="")
+    ap.add_argument("--csv", default="", help="also write every kernel's per-step totals to this file")
     a = ap.parse_args()
     db = sqlite3.connect(a.db)
     agg = collections.defaultdict(lambda: [0, 0])
@@ -27,6 +28,11 @@ def main():
     total = sum(v[1] for v in agg.values())
     print(f"kernel time per step: {total / 1e6 / a.steps:.3f} ms, launches per step: {sum(v[0] for v in agg.values()) / a.steps:.0f}")
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    if a.csv:
+        with open(a.csv, "w") as f:
+            f.write("kernel,launches_per_step,ms_per_step,avg_us\n")
+            for name, (cnt, ns) in rows:
+                f.write(f"\"{name}\",{cnt / a.steps:.2f},{ns / 1e6 / a.steps:.4f},{ns / cnt / 1e3:.2f}\n")
     if a.match:
         rows = [r for r in rows if a.match in r[0]]
     for name, (cnt, ns) in rows[:a.top]:

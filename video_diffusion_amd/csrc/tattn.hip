@@ -338,7 +338,11 @@ __global__ __launch_bounds__(NWAVES * 64) void tattn_fused_kernel(const TAttnArg
         }
 
         // ---- residual + store: registers (4u+v) of tile ct hold channel 32ct + 16(u>>1) + 8 half + 4(u&1) + v
+#ifdef VDMI_TA_ABL_NOSTORE      // timing-only ablation (wrong results): neither the residual reads nor the stores
+        if (rowvalid && a.eps < -1.f) {
+#else
         if (rowvalid) {
+#endif
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll

@@ -17,7 +17,8 @@
 //     (lane = feature) that the transposing LDS read ds_read_b64_tr_b16 returns from a [token][feature] image whose
 //     rows are stored in that same order:  O^T = V^T P^T,  dQ^T = K^T dS^T,  dV^T = dO^T P,  dK^T = Q^T dS;
 //   * results come out with lane = token, registers = 16 features (a rotary pair in one lane again): inverse rotation,
-//     8-byte stores;
+//     then through LDS to 16-byte stores with four lanes on a row's 64 bytes (stores of 8 bytes per row and instruction
+//     cost the memory system a partial-line write each: as much time as all the loads of the kernel);
 //   * the bias gradient dS is summed in registers over all units of the wave and written once as a [32 x 32] partial;
 //     a second launch adds the partials of a head (and the g diagonal blocks) in a fixed order - no atomics.
 #include "vdmi_common.h"
