@@ -471,12 +471,15 @@ int vdmi_pack_taps_device(const float* w, int n, int npad, int cin0, int cin1, i
  * two hundred sets, most of them a few microseconds of work).  Each job is one vdmi_pack_taps_device call; in_scale
  * (device float [cin0 + cin1] over the FORWARD weight's input channels, or NULL) multiplies every element by the factor of
  * its input channel - the LayerNorm gamma that the attention layers fold into to_qkv (vdp.py:386-389, 546) - so the
- * folded weight never exists as a tensor.  `jobs` is host memory; device_table: vdmi_pack_taps_batch_table_bytes(count)
+ * folded weight never exists as a tensor.  gather (device int32 [n][cin0 + cin1][ntaps], or NULL): the set's source tensor
+ * is a re-arrangement of w, element e of it being w[gather[e]] - the space-to-depth view of Downsample's (1,4,4) kernel
+ * and the four per-parity tap sets of Upsample's (vdp.py:374-378) come straight from the parameter.  `jobs` is host memory; device_table: vdmi_pack_taps_batch_table_bytes(count)
  * bytes of device memory that the launch reads (keep it until the stream has passed the call).  Has no counterpart in
  * the reference (torch keeps one weight layout). */
 typedef struct vdmi_pack_job {
     const float* w;
     const float* in_scale;
+    const int32_t* gather;
     void* out;
     int n, npad, cin0, cin1, ntaps, bkc, transposed;
 } vdmi_pack_job;

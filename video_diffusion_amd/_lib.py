@@ -77,7 +77,7 @@ class DdpmCoefs(C.Structure):
 
 class PackJob(C.Structure):
     """include/vdmi.h: vdmi_pack_job"""
-    _fields_ = [("w", C.c_void_p), ("in_scale", C.c_void_p), ("out", C.c_void_p),
+    _fields_ = [("w", C.c_void_p), ("in_scale", C.c_void_p), ("gather", C.c_void_p), ("out", C.c_void_p),
                 ("n", C.c_int), ("npad", C.c_int), ("cin0", C.c_int), ("cin1", C.c_int), ("ntaps", C.c_int),
                 ("bkc", C.c_int), ("transposed", C.c_int)]
 

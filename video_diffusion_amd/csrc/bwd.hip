@@ -27,7 +27,10 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------
 // `in_scale` (float [cin0 + cin1] of the FORWARD weight's input channels, or null) multiplies every element by the
 // factor of its input channel: a LayerNorm gamma folded into the projection that follows it
-__device__ __forceinline__ void pack_taps_piece(const float* __restrict__ w, const float* __restrict__ in_scale, int n, int npad,
+// `gather` (int32 [n][cin0 + cin1][ntaps], or null): the weight set is a re-arrangement of a parameter - element e of the
+// set's source tensor is w[gather[e]] (the space-to-depth and per-phase views of the resampling convolutions' kernels)
+__device__ __forceinline__ void pack_taps_piece(const float* __restrict__ w, const float* __restrict__ in_scale,
+                                                const int* __restrict__ gather, int n, int npad,
                                                 int cin0, int cin1, int ntaps, int bkc, int transposed,
                                                 __bf16* __restrict__ out, long long o8) {
     const int ks_per = bkc / 16, nct = npad / 32, nch0 = (cin0 + bkc - 1) / bkc;
@@ -50,8 +53,9 @@ __device__ __forceinline__ void pack_taps_piece(const float* __restrict__ w, con
         if (co < n && ci < clim) {
             // transposed: `w` is the forward convolution's weight [cin][n][ntaps] seen from its output side, taps reversed
             // (this pass's output channel co is the forward weight's input channel)
-            f = transposed ? w[((size_t)(coff + ci) * n + co) * ntaps + (ntaps - 1 - t)]
-                           : w[((size_t)co * cin + coff + ci) * ntaps + t];
+            const size_t e = transposed ? ((size_t)(coff + ci) * n + co) * ntaps + (ntaps - 1 - t)
+                                        : ((size_t)co * cin + coff + ci) * ntaps + t;
+            f = w[gather ? (size_t)gather[e] : e];
             if (in_scale) f *= transposed ? in_scale[co] : in_scale[coff + ci];
         }
         v[j] = f2bf(f);
@@ -64,18 +68,19 @@ __global__ __launch_bounds__(256) void pack_taps_kernel(const float* __restrict_
                                                         long long pieces) {
     const long long o8 = (long long)blockIdx.x * 256 + threadIdx.x;
     if (o8 >= pieces) return;
-    pack_taps_piece(w, nullptr, n, npad, cin0, cin1, ntaps, bkc, transposed, out, o8);
+    pack_taps_piece(w, nullptr, nullptr, n, npad, cin0, cin1, ntaps, bkc, transposed, out, o8);
 }
 
 // many weight sets in one launch: the job table (device copy of vdmi_pack_job records) is sorted by first workgroup
 struct PackJobDev {
     const float* w;
     const float* in_scale;
+    const int* gather;
     __bf16* out;
     long long pieces, block_begin;
     int n, npad, cin0, cin1, ntaps, bkc, transposed, pad_;
 };
-static_assert(sizeof(PackJobDev) == 72, "job record");
+static_assert(sizeof(PackJobDev) == 80, "job record");
 
 __global__ __launch_bounds__(256) void pack_taps_batch_kernel(const PackJobDev* __restrict__ jobs, int count) {
     int lo = 0, hi = count - 1;                 // the last job whose first workgroup is <= this one
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void pack_taps_batch_kernel(const PackJobDev* 
     const PackJobDev j = jobs[lo];
     const long long o8 = ((long long)blockIdx.x - j.block_begin) * 256 + threadIdx.x;
     if (o8 >= j.pieces) return;
-    pack_taps_piece(j.w, j.in_scale, j.n, j.npad, j.cin0, j.cin1, j.ntaps, j.bkc, j.transposed, j.out, o8);
+    pack_taps_piece(j.w, j.in_scale, j.gather, j.n, j.npad, j.cin0, j.cin1, j.ntaps, j.bkc, j.transposed, j.out, o8);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -723,6 +728,7 @@ extern "C" int vdmi_pack_taps_batch(const vdmi_pack_job* jobs, int count, void* 
         PackJobDev& d = tab[(size_t)i];
         d.w = j.w;
         d.in_scale = j.in_scale;
+        d.gather = j.gather;
         d.out = static_cast<__bf16*>(j.out);
         d.pieces = (long long)vdmi_pack_taps_elems(j.n, j.npad, j.cin0, j.cin1, j.ntaps, j.bkc) / 8;
         d.block_begin = blocks;

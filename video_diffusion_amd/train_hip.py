@@ -74,12 +74,16 @@ def torch_ops(fn, *xs):
 class DevPack:
     """A weight set in the tap-GEMM's fragment order, packed on the device (weights change every optimizer step)."""
 
-    def __init__(self, weight: torch.Tensor, transposed: bool, tile_bn=None, in_scale=None, fill=True):
+    def __init__(self, weight: torch.Tensor, transposed: bool, tile_bn=None, in_scale=None, fill=True, gather=None,
+                 shape=None, data=None):
         # weight: a Conv3d weight (cout, cin, 1, kh, kw), or the same as [cout][cin][taps].  transposed: the set of the
         # input-gradient pass.  tile_bn: 64 forces 64-channel output tiles, 0 the automatic tile, None picks by width.
-        # in_scale: float [cin] factors of the weight's input channels, multiplied in while packing (a folded gamma)
-        cout, cin = weight.shape[0], weight.shape[1]
-        ntaps = weight[0, 0].numel()
+        # in_scale: float [cin] factors of the weight's input channels, multiplied in while packing (a folded gamma).
+        # gather: int32 [cout][cin][taps] with shape = (cout, cin, taps): the set's source is the re-arrangement
+        # weight.flatten()[gather] of a parameter (never built as a tensor).  data: a bf16 slice to pack into.
+        cout, cin, ntaps = shape if shape is not None else (weight.shape[0], weight.shape[1], weight[0, 0].numel())
+        self.src_shape = (cout, cin, ntaps)
+        self.gather = gather
         self.transposed = bool(transposed)
         self.n, self.k = (cin, cout) if transposed else (cout, cin)
         self.ntaps = ntaps
@@ -91,29 +95,33 @@ class DevPack:
             check(_lib.lib().vdmi_tapgemm_tile(EPI_PLAIN, self.n, C.byref(bn), C.byref(bkc)), "vdmi_tapgemm_tile")
             self.bn, self.bkc = bn.value, bkc.value
         self.npad = (self.n + self.bn - 1) // self.bn * self.bn
-        elems = _lib.lib().vdmi_pack_taps_elems(self.n, self.npad, self.k, 0, ntaps, self.bkc)
-        self.data = torch.empty(elems, dtype=torch.bfloat16, device=weight.device)
+        self.elems = _lib.lib().vdmi_pack_taps_elems(self.n, self.npad, self.k, 0, ntaps, self.bkc)
+        self.data = data
         self._keep = None
         if fill:
             self.fill(weight, in_scale)
 
     def job(self, weight: torch.Tensor, in_scale=None) -> "_lib.PackJob":
         """The vdmi_pack_job that fills this set from `weight`; the float32 tensors it reads stay referenced by the set."""
-        w3 = weight.detach().reshape(weight.shape[0], weight.shape[1], self.ntaps).to(torch.float32).contiguous()
+        if self.data is None:
+            self.data = torch.empty(self.elems, dtype=torch.bfloat16, device=weight.device)
+        cout, cin, ntaps = self.src_shape
+        w3 = weight.detach().to(torch.float32).contiguous()
+        assert self.gather is not None or w3.numel() == cout * cin * ntaps
         sc = None if in_scale is None else in_scale.detach().reshape(-1).to(torch.float32).contiguous()
-        assert sc is None or sc.numel() == weight.shape[1]
+        assert sc is None or sc.numel() == cin
         self._keep = (w3, sc)
-        return _lib.PackJob(w3.data_ptr(), None if sc is None else sc.data_ptr(), self.data.data_ptr(), self.n, self.npad,
-                            self.k, 0, self.ntaps, self.bkc, 1 if self.transposed else 0)
+        return _lib.PackJob(w3.data_ptr(), None if sc is None else sc.data_ptr(),
+                            None if self.gather is None else self.gather.data_ptr(), self.data.data_ptr(), self.n,
+                            self.npad, self.k, 0, self.ntaps, self.bkc, 1 if self.transposed else 0)
 
     def fill(self, weight: torch.Tensor, in_scale=None):
-        lib = _lib.lib()
-        if in_scale is None:
-            j = self.job(weight)
-            check(lib.vdmi_pack_taps_device(j.w, j.n, j.npad, j.cin0, j.cin1, j.ntaps, j.bkc, j.transposed, j.out, _stream()),
-                  "vdmi_pack_taps_device")
+        j = self.job(weight, in_scale)
+        if in_scale is None and self.gather is None:
+            check(_lib.lib().vdmi_pack_taps_device(j.w, j.n, j.npad, j.cin0, j.cin1, j.ntaps, j.bkc, j.transposed, j.out,
+                                                   _stream()), "vdmi_pack_taps_device")
         else:
-            pack_batch([self.job(weight, in_scale)], weight.device)
+            pack_batch([j], weight.device)
 
 
 def pack_batch(jobs, device):
@@ -123,6 +131,21 @@ def pack_batch(jobs, device):
     table = torch.empty(lib.vdmi_pack_taps_batch_table_bytes(len(jobs)), device=device, dtype=torch.uint8)
     check(lib.vdmi_pack_taps_batch(C.cast(arr, C.c_void_p), len(jobs), table.data_ptr(), _stream()), "vdmi_pack_taps_batch")
     return table
+
+
+class PhasePacks:
+    """Several weight sets re-arranged from ONE parameter (the four output parities of the transposed convolution), back to
+    back in one buffer: `data`, sets `stride` elements apart."""
+
+    def __init__(self, weight: torch.Tensor, gathers, shape, tile_bn):
+        self.packs = [DevPack(weight, False, tile_bn, fill=False, gather=g, shape=shape) for g in gathers]
+        self.stride = self.packs[0].elems
+        self.data = torch.empty(self.stride * len(gathers), dtype=torch.bfloat16, device=weight.device)
+        for i, p in enumerate(self.packs):
+            p.data = self.data[i * self.stride:(i + 1) * self.stride]
+
+    def jobs(self, weight):
+        return [p.job(weight) for p in self.packs]
 
 
 class PackStore:
@@ -157,22 +180,38 @@ class PackStore:
         e.wv = e.weight._version
         e.sv = None if e.scale is None else e.scale._version
 
-    def get(self, weight: torch.Tensor, transposed: bool, tile_bn=None, in_scale=None) -> DevPack:
-        key = (weight.data_ptr(), tuple(weight.shape), bool(transposed), tile_bn,
-               None if in_scale is None else in_scale.data_ptr())
+    @staticmethod
+    def _jobs(e):
+        return e.pack.jobs(e.weight) if isinstance(e.pack, PhasePacks) else [e.pack.job(e.weight, e.scale)]
+
+    def _entry(self, key, weight, in_scale, make):
         e = self.entries.get(key)
         if e is None:
             e = PackStore._Entry()
-            e.pack = DevPack(weight, transposed, tile_bn, fill=False)
+            e.pack = make()
             # aliases of the caller's tensors: they share the version counters and keep the memory (and with it the key) theirs
             e.weight, e.scale = weight.detach(), None if in_scale is None else in_scale.detach()
             e.wv = -1
             self.entries[key] = e
         e.age = 0
         if self._stale(e):
-            e.pack.fill(e.weight, e.scale)
+            jobs = self._jobs(e)
+            if len(jobs) == 1 and e.scale is None and e.pack.gather is None:
+                e.pack.fill(e.weight)
+            else:
+                pack_batch(jobs, e.weight.device)
             self._stamp(e)
         return e.pack
+
+    def get(self, weight: torch.Tensor, transposed: bool, tile_bn=None, in_scale=None, gather=None, shape=None) -> DevPack:
+        key = (weight.data_ptr(), tuple(weight.shape), bool(transposed), tile_bn,
+               None if in_scale is None else in_scale.data_ptr(), None if gather is None else gather.data_ptr())
+        return self._entry(key, weight, in_scale,
+                           lambda: DevPack(weight, transposed, tile_bn, fill=False, gather=gather, shape=shape))
+
+    def get_phases(self, weight: torch.Tensor, gathers, shape, tile_bn) -> PhasePacks:
+        key = (weight.data_ptr(), tuple(weight.shape), "phases", tile_bn, None, gathers[0].data_ptr())
+        return self._entry(key, weight, None, lambda: PhasePacks(weight, gathers, shape, tile_bn))
 
     def refresh(self):
         """Repack every stale set in one launch; sets no caller asked for since the refresh before the last are dropped."""
@@ -183,7 +222,7 @@ class PackStore:
             e.age += 1
         if not stale:
             return
-        self._table = pack_batch([e.pack.job(e.weight, e.scale) for e in stale], stale[0].weight.device)
+        self._table = pack_batch([j for e in stale for j in self._jobs(e)], stale[0].weight.device)
         for e in stale:
             self._stamp(e)
 
@@ -212,11 +251,19 @@ class fixed_weights:
         return False
 
 
-def param_pack(weight: torch.Tensor, transposed: bool, tile_bn=None, in_scale=None) -> DevPack:
+def param_pack(weight: torch.Tensor, transposed: bool, tile_bn=None, in_scale=None, gather=None, shape=None) -> DevPack:
     """DevPack of a parameter, through the store of an enclosing fixed_weights block when there is one."""
     if _PACKS is None:
-        return DevPack(weight, transposed, tile_bn, in_scale)
-    return _PACKS.get(weight, transposed, tile_bn, in_scale)
+        return DevPack(weight, transposed, tile_bn, in_scale, gather=gather, shape=shape)
+    return _PACKS.get(weight, transposed, tile_bn, in_scale, gather, shape)
+
+
+def phase_packs(weight: torch.Tensor, gathers, shape, tile_bn) -> PhasePacks:
+    if _PACKS is not None:
+        return _PACKS.get_phases(weight, gathers, shape, tile_bn)
+    ph = PhasePacks(weight, gathers, shape, tile_bn)
+    pack_batch(ph.jobs(weight), weight.device)
+    return ph
 
 
 def conv_rows(src: torch.Tensor, pack: DevPack, bias, frames: int, fpb: int, h: int, w: int, residual=None) -> torch.Tensor:
@@ -927,17 +974,35 @@ def temporal_attention(res, x: torch.Tensor, pos_bias, rot_tables, focus=None) -
 _UP_PAIRS = {0: [(1, 0), (3, -1)], 1: [(0, 1), (2, 0)]}     # output parity -> (kernel index, input offset) pairs
 
 
+_GATHERS = {}
+
+
+def _resample_gathers(kind: str, weight: torch.Tensor):
+    """Index tables (int32, positions in the flattened parameter) of the weight sets the resampling convolutions run on:
+    "down": [n][4 cin][4 taps], the 2x2 / stride-1 kernel over the space-to-depth view; "up": four [n][cin][4 taps], one
+    per output parity.  The re-arrangement is applied to an index tensor once per shape and device."""
+    key = (kind, tuple(weight.shape), weight.device)
+    hit = _GATHERS.get(key)
+    if hit is None:
+        idx = torch.arange(weight.numel(), dtype=torch.int32, device=weight.device).view(weight.shape)[:, :, 0]
+        if kind == "down":
+            hit = [torch.cat([torch.stack([idx[:, :, 2 * dy + a, 2 * dx + b] for dy in (0, 1) for dx in (0, 1)], dim=-1)
+                              for a in (0, 1) for b in (0, 1)], dim=1).contiguous()]
+        else:
+            hit = [torch.stack([idx[:, :, ky, kx].t() for (ky, _) in _UP_PAIRS[pp] for (kx, _) in _UP_PAIRS[q]], dim=-1).contiguous()
+                   for pp in (0, 1) for q in (0, 1)]
+        _GATHERS[key] = hit
+    return hit
+
+
 def down_conv_rows(x: torch.Tensor, weight: torch.Tensor, bias, frames: int, fpb: int, h: int, w: int) -> torch.Tensor:
     """Conv3d(cin, n, (1,4,4), stride 2, pad 1) over rows of an h x w image -> rows of the (h/2) x (w/2) image, as a
     2x2 / stride-1 tap-GEMM over the space-to-depth view of x.  weight (n, cin, 1, 4, 4)."""
     n, cin = weight.shape[0], weight.shape[1]
     if h % 2 or w % 2 or cin % 64:
         raise _lib.VdmiError("the HIP resampling convolutions take even images and channel widths that are multiples of 64")
-    w4 = weight.detach()[:, :, 0].float()
-    # channel (2a+b)*cin + ci, tap (dY, dX)  <-  kernel element (2dY+a, 2dX+b)
-    w2 = torch.cat([torch.stack([w4[:, :, 2 * dy + a, 2 * dx + b] for dy in (0, 1) for dx in (0, 1)], dim=-1)
-                    for a in (0, 1) for b in (0, 1)], dim=1)
-    pack = DevPack(w2, False, tile_bn=64)
+    # channel (2a+b)*cin + ci, tap (dY, dX)  <-  kernel element (2dY+a, 2dX+b): an index table, the packer gathers
+    pack = param_pack(weight, False, 64, gather=_resample_gathers("down", weight)[0], shape=(n, 4 * cin, 4))
     oh, ow = h // 2, w // 2
     out = torch.empty(frames * oh * ow, n, device=x.device, dtype=torch.bfloat16)
     a = TapGemmArgs()
@@ -962,13 +1027,9 @@ def up_conv_rows(x: torch.Tensor, weight: torch.Tensor, bias, frames: int, fpb: 
     """ConvTranspose3d(cin, n, (1,4,4), stride 2, pad 1) over rows of an h x w image -> rows of the 2h x 2w image: the four
     output parities as four 4-tap phases of one launch.  weight (cin, n, 1, 4, 4)."""
     cin, n = weight.shape[0], weight.shape[1]
-    w4 = weight.detach()[:, :, 0].float()
-    packs = []
-    for pp in (0, 1):
-        for q in (0, 1):
-            taps = torch.stack([w4[:, :, ky, kx].t() for (ky, _) in _UP_PAIRS[pp] for (kx, _) in _UP_PAIRS[q]], dim=-1)
-            packs.append(DevPack(taps, False, tile_bn=0).data)
-    wall = torch.cat(packs).contiguous()
+    # one 4-tap weight set [n][cin][tap] per output parity (pp, q), gathered from the parameter by index tables
+    ph = phase_packs(weight, _resample_gathers("up", weight), (n, cin, 4), 0)
+    wall = ph.data
     oh, ow = 2 * h, 2 * w
     out = torch.empty(frames * oh * ow, n, device=x.device, dtype=torch.bfloat16)
     taps = [(dy, dx) for pp in (0, 1) for q in (0, 1) for (_, dy) in _UP_PAIRS[pp] for (_, dx) in _UP_PAIRS[q]]
@@ -983,7 +1044,7 @@ def up_conv_rows(x: torch.Tensor, weight: torch.Tensor, bias, frames: int, fpb: 
     for i, (dy, dx) in enumerate(taps):
         p.dy[i], p.dx[i] = dy, dx
     p.w = wall.data_ptr()
-    p.phases, p.w_phase_stride = 4, packs[0].numel()
+    p.phases, p.w_phase_stride = 4, ph.stride
     a.bias = None if bias is None else bias.data_ptr()
     check(_lib.lib().vdmi_tapgemm(C.byref(a), _stream()), "vdmi_tapgemm")
     return out
@@ -1003,15 +1064,13 @@ def strided_wgrad(big: torch.Tensor, small: torch.Tensor, frames: int, h: int, w
     # shifted row wraps into the next image row or frame, the other factor is zero
     s2d, sp = s2d.contiguous(), sp.contiguous()
     total = s2d.shape[0]
-    dw = torch.empty(cs, cb, 4, 4, device=big.device, dtype=torch.float32)
+    d2 = []
     for ty in (0, 1):
         for tx in (0, 1):
             shift = ty * (ow + 1) + tx
-            d2 = rows_wgrad(s2d[shift:], sp[:total - shift]).view(cs, 2, 2, cb)
-            for a in (0, 1):
-                for b in (0, 1):
-                    dw[:, :, 2 * ty + a, 2 * tx + b] = d2[:, a, b]
-    return dw.view(cs, cb, 1, 4, 4)
+            d2.append(rows_wgrad(s2d[shift:], sp[:total - shift]))              # [cs][(a, b, cb)]
+    # [ty][tx][cs][a][b][cb] -> [cs][cb][2 ty + a][2 tx + b]
+    return torch.stack(d2).view(2, 2, cs, 2, 2, cb).permute(2, 5, 0, 3, 1, 4).reshape(cs, cb, 1, 4, 4)
 
 
 class DownsampleFn(torch.autograd.Function):
