@@ -345,9 +345,14 @@ def main():
 
     if rank == 0:
         classes = measure(plan, max(3, min(args.steps, 10)))
-        # dominant kernel: the matrix-core kernel class with the largest share of the step
+        # dominant kernel: the matrix-core kernel class with the largest share of the step.  Two classes of this step lie
+        # within a percent of each other (the streaming convolution and the fused temporal attention, ~1.0 ms each), and
+        # which of them is ahead changes from device to device: among the classes within 2 % of the longest the one with
+        # the most matrix work is named, the other is reported beside it (`runner_up`).
         mfma_classes = [k for k in classes if classes[k]["flops_per_step"] > 0]
-        dom_key = max(mfma_classes, key=lambda k: classes[k]["ms_per_step"])
+        top_ms = max(classes[k]["ms_per_step"] for k in mfma_classes)
+        near = [k for k in mfma_classes if classes[k]["ms_per_step"] >= 0.98 * top_ms]
+        dom_key = max(near, key=lambda k: classes[k]["flops_per_step"])
         dom = classes[dom_key]
         avg_ms = dom["ms_per_step"] / dom["launches_per_step"]
         achieved = dom["flops_per_step"] / (dom["ms_per_step"] * 1e-3) / 1e12
@@ -367,6 +372,13 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": dom["launches_per_step"],
                     "videos_per_launch": B // parts,
                     "algorithmic_gflop_per_launch": round(dom["flops_per_step"] / dom["launches_per_step"] / 1e9, 2)}
+        others = sorted((k for k in mfma_classes if k != dom_key), key=lambda k: -classes[k]["ms_per_step"])
+        if others:
+            ru = classes[others[0]]
+            ru_tf = ru["flops_per_step"] / (ru["ms_per_step"] * 1e-3) / 1e12
+            roofline["runner_up"] = {"kernel": others[0], "ms_per_step": round(ru["ms_per_step"], 4),
+                                     "achieved": round(ru_tf, 2), "frac": round(ru_tf / PEAK_BF16_TFLOPS, 4)}
+            roofline["ms_per_step"] = round(dom["ms_per_step"], 4)
         # beside the nominal peak: what an operand-free MFMA loop reaches on this device (tools/peak_probe.hip)
         ppath = os.path.join(ROOT, "profiles", "peak_probe.json")
         if os.path.exists(ppath):
