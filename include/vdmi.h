@@ -607,6 +607,10 @@ int vdmi_sla_train_rows_fwd(const void* qkv, const void* combined_ctx, void* out
 int vdmi_sla_train_rows_bwd(const void* qkv, const void* qt, const void* dout, const void* combined_ctx,
                             const void* combined_dctx, void* dqkv, int frames, int n, int heads, float scale,
                             vdmi_stream stream);
+/* HOST. Tests / A-B runs: 0 keeps vdmi_sla_train_rows_fwd / _bwd on the vector kernels (one lane per (row, head)), 1 allows
+ * the matrix-core form again (tiles of 32 rows of one head, the 32 x 32 context as a high + low pair of 16-bit operands);
+ * VDMI_SLA_ROWS_MFMA=0 in the environment does the same.  No counterpart in the reference. */
+void vdmi_sla_rows_mfma_enable(int on);
 
 #ifdef __cplusplus
 }

@@ -412,11 +412,23 @@ def test_resampling_convs_forward_backward_vs_torch(c, f, h, w):
         assert record(tag + ".db", rel_err(mod.bias.grad, ref[3]), 1e-2) < 1e-2
 
 
-@pytest.mark.parametrize("frames,n,heads", [(3, 100, 4), (2, 2500, 4), (5, 64, 8), (16, 4096, 4)])
-def test_sla_core_forward_backward_vs_torch(frames, n, heads):
-    """The linear-attention core (vdp.py:467-477) on raw q, k, v rows: reduction partials + row kernels against torch."""
+@pytest.mark.parametrize("form", ["mfma", "vector"])
+@pytest.mark.parametrize("frames,n,heads", [(3, 100, 4), (2, 2500, 4), (5, 64, 8), (16, 4096, 4), (7, 33, 8), (1, 1, 2)])
+def test_sla_core_forward_backward_vs_torch(frames, n, heads, form):
+    """The linear-attention core (vdp.py:467-477) on raw q, k, v rows: reduction partials + row kernels against torch, with
+    the row kernels on the matrix cores (tiles of 32 rows, ragged last tiles, runs of tiles that cross frames) and on
+    the vector kernels."""
     from video_diffusion_amd import _lib
     lib = _lib.lib()
+    lib.vdmi_sla_rows_mfma_enable(1 if form == "mfma" else 0)
+    try:
+        _sla_core_case(lib, frames, n, heads, form)
+    finally:
+        lib.vdmi_sla_rows_mfma_enable(1)
+
+
+def _sla_core_case(lib, frames, n, heads, form):
+    from video_diffusion_amd import _lib
     g = torch.Generator().manual_seed(15)
     rows, hid, scale = frames * n, heads * 32, 32 ** -0.5
     qkv = _bf(torch.randn(rows, 3 * hid, generator=g) * 1.5).to(DEV)
@@ -436,7 +448,7 @@ def test_sla_core_forward_backward_vs_torch(frames, n, heads):
     ctx = torch.einsum("bhdn,bhen->bhde", k, v)
     ref = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(rows, hid)
     ref.backward(dout.double())
-    tag = f"sla_core.n{n}.h{heads}"
+    tag = f"sla_core.{form}.f{frames}.n{n}.h{heads}"
     assert record(tag + ".out", rel_err(out.float().cpu(), ref.detach().cpu()), 5e-3) < 5e-3
     assert record(tag + ".dqkv", rel_err(dqkv.float().cpu(), qr.grad.cpu()), 1.5e-2) < 1.5e-2
 

@@ -197,6 +197,7 @@ _SIGNATURES = {
                               [C.c_int] * 4 + [C.c_void_p]),
     "vdmi_sla_train_rows_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "vdmi_sla_train_rows_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
+    "vdmi_sla_rows_mfma_enable": (None, [C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -723,9 +723,18 @@ extern "C" int vdmi_sla_train_reduce(const void* a, int lda, const void* b, int 
     return VDMI_OK;
 }
 
+// sla_rows_mfma.hip: the matrix-core form of the row kernels
+bool vdmi_sla_rows_mfma_covers(int frames, int n, int heads);
+int vdmi_sla_rows_mfma_launch(bool bwd, const void* qkv, const void* qt, const void* dout, const void* rec_ctx,
+                              const void* rec_dctx, void* out, void* qt_out, int frames, int n, int heads, float scale,
+                              hipStream_t stream);
+
 static int sla_rows_launch(bool bwd, SlaRowsArgs& r, hipStream_t stream) {
     const int st = sla_shape_check(r.frames, r.n, r.heads);
     if (st != VDMI_OK) return st;
+    if (vdmi_sla_rows_mfma_covers(r.frames, r.n, r.heads))
+        return vdmi_sla_rows_mfma_launch(bwd, r.qkv, r.qt, r.dout, r.comb_ctx, r.comb_dctx, r.out, r.qt_out, r.frames, r.n,
+                                         r.heads, r.scale, stream);
     const int rb = 256 / r.heads;
     const int blocks = (r.n + rb - 1) / rb;
     // each workgroup first copies its frame's combined records (4-9 KB per head) into LDS: several row blocks per workgroup
