@@ -687,6 +687,14 @@ int sla_shape_check(int frames, int n, int heads) {
 
 }   // namespace
 
+// sla_rows_mfma.hip: the matrix-core forms of the row kernels and of the sums over positions
+bool vdmi_sla_rows_mfma_covers(int frames, int n, int heads);
+int vdmi_sla_rows_mfma_launch(bool bwd, const void* qkv, const void* qt, const void* dout, const void* rec_ctx,
+                              const void* rec_dctx, void* out, void* qt_out, int frames, int n, int heads, float scale,
+                              hipStream_t stream);
+int vdmi_sla_reduce_mfma_launch(bool softmax, const void* a, int lda, const void* b, int ldb, float* part, int frames, int n,
+                                int heads, int nsplit, int split_len, hipStream_t stream);
+
 extern "C" size_t vdmi_sla_train_partial_bytes(int frames, int n, int heads) {
     if (sla_shape_check(frames, n, heads) != VDMI_OK) return 0;
     const size_t nsplit = (size_t)(n + SLA_SPLIT - 1) / SLA_SPLIT;
@@ -712,22 +720,21 @@ extern "C" int vdmi_sla_train_reduce(const void* a, int lda, const void* b, int 
     hipStream_t s = static_cast<hipStream_t>(stream);
     SlaRedArgs r{static_cast<const __bf16*>(a), lda, static_cast<const __bf16*>(b), ldb, static_cast<float*>(partials), n, heads,
                  (n + SLA_SPLIT - 1) / SLA_SPLIT};
-    const dim3 grid((unsigned)r.nsplit, (unsigned)heads, (unsigned)frames);
-    if (mode == 0) hipLaunchKernelGGL(sla_reduce_kernel<true>, grid, dim3(256), 0, s, r);
-    else hipLaunchKernelGGL(sla_reduce_kernel<false>, grid, dim3(256), 0, s, r);
-    VDMI_LAUNCH_CHECK();
+    if (vdmi_sla_rows_mfma_covers(frames, n, heads)) {
+        const int st2 = vdmi_sla_reduce_mfma_launch(mode == 0, a, lda, b, ldb, r.part, frames, n, heads, r.nsplit, SLA_SPLIT, s);
+        if (st2 != VDMI_OK) return st2;
+    } else {
+        const dim3 grid((unsigned)r.nsplit, (unsigned)heads, (unsigned)frames);
+        if (mode == 0) hipLaunchKernelGGL(sla_reduce_kernel<true>, grid, dim3(256), 0, s, r);
+        else hipLaunchKernelGGL(sla_reduce_kernel<false>, grid, dim3(256), 0, s, r);
+        VDMI_LAUNCH_CHECK();
+    }
     SlaCombArgs c{static_cast<const float*>(partials), static_cast<const float*>(combined_ctx), static_cast<float*>(combined),
                   heads, r.nsplit, mode};
     hipLaunchKernelGGL(sla_combine_kernel, dim3((unsigned)heads, (unsigned)frames), dim3(256), 0, s, c);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
-
-// sla_rows_mfma.hip: the matrix-core form of the row kernels
-bool vdmi_sla_rows_mfma_covers(int frames, int n, int heads);
-int vdmi_sla_rows_mfma_launch(bool bwd, const void* qkv, const void* qt, const void* dout, const void* rec_ctx,
-                              const void* rec_dctx, void* out, void* qt_out, int frames, int n, int heads, float scale,
-                              hipStream_t stream);
 
 static int sla_rows_launch(bool bwd, SlaRowsArgs& r, hipStream_t stream) {
     const int st = sla_shape_check(r.frames, r.n, r.heads);

@@ -250,9 +250,143 @@ __global__ __launch_bounds__(SR_WAVES * 64) void sla_rows_mfma_kernel(const SrAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The sums over a frame's positions on the matrix cores:  part[d][e] = sum_n w[n][d] b[n][e]  over one split of 1024
+// positions, w = exp(a - running maximum per feature d) (SOFTMAX: a = k, b = v, with the maximum and the weight sum
+// kept beside the sums, as the vector kernel leaves them for the combine launch) or w = a (a = Qt, b = gradient of out).
+// The contraction index is the ROW, so both operands are the transposed tiles that ds_read_b64_tr_b16 returns from
+// [row][feature] LDS images (lane = feature, 8 rows): per-feature maxima and weight sums are then lane-local.  One wave
+// per (frame, head, split), the eight waves of a workgroup on eight heads of the same rows; the next tile's rows are
+// requested before the current tile's products.
+// ------------------------------------------------------------------------------------------------------------------
+typedef short s4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_fragment(const char* base) {
+    typedef __attribute__((address_space(3))) s4v* lds_s4;
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base + 4 * 64));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+struct SredArgs {
+    const __bf16* a; int lda;
+    const __bf16* b; int ldb;
+    float* part;              // [frame][head][split][SR_REC]
+    int n, heads, nsplit, split_len;
+};
+
+template <bool SOFTMAX>
+__global__ __launch_bounds__(SR_WAVES * 64) void sla_reduce_mfma_kernel(const SredArgs a) {
+    __shared__ __attribute__((aligned(16))) char img[SR_WAVES][2][32 * 64];
+    __shared__ __attribute__((aligned(16))) float corr_l[SR_WAVES][32];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x, head = blockIdx.y * SR_WAVES + wave, frame = blockIdx.z;
+    if (head >= a.heads) return;
+    const int p_begin = split * a.split_len, p_end = min(p_begin + a.split_len, a.n);
+    const int p_row = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int wr_off = p_row * 64 + 16 * half;
+    const int g16 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int tr_off = (8 * (g16 >> 1) + tq) * 64 + (16 * (g16 & 1) + 4 * tp) * 2;
+    char* ia = img[wave][0];
+    char* ib = img[wave][1];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float M = -1e30f, z = 0.f;                      // of feature d = l31 (the same in both halves of the wave)
+
+    bf16x8 na0 = zero8, na1 = zero8, nb0 = zero8, nb1 = zero8;
+    auto fetch = [&](int p0) {
+        const int pos = p0 + l31;
+        na0 = na1 = nb0 = nb1 = zero8;
+        if (p0 < p_end && pos < p_end) {
+            const long long row = (long long)frame * a.n + pos;
+            const __bf16* pa = a.a + row * a.lda + head * 32 + 8 * half;
+            const __bf16* pb = a.b + row * a.ldb + head * 32 + 8 * half;
+            na0 = *reinterpret_cast<const bf16x8*>(pa);
+            na1 = *reinterpret_cast<const bf16x8*>(pa + 16);
+            nb0 = *reinterpret_cast<const bf16x8*>(pb);
+            nb1 = *reinterpret_cast<const bf16x8*>(pb + 16);
+        }
+    };
+    fetch(p_begin);
+    for (int p0 = p_begin; p0 < p_end; p0 += 32) {
+        const bf16x8 a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
+        const int nvalid = p_end - p0;              // rows of this tile that exist (>= 32: all)
+        fetch(p0 + 32);
+        *reinterpret_cast<bf16x8*>(ia + wr_off) = a0;
+        *reinterpret_cast<bf16x8*>(ia + wr_off + 32) = a1;
+        *reinterpret_cast<bf16x8*>(ib + wr_off) = b0;
+        *reinterpret_cast<bf16x8*>(ib + wr_off + 32) = b1;
+        // lane = feature; element j of k-step s is the row acc_row(8 s + j, half) of the tile
+        const bf16x8 at0 = tr_fragment(ia + tr_off), at1 = tr_fragment(ia + tr_off + 16 * 64);
+        const bf16x8 bt0 = tr_fragment(ib + tr_off), bt1 = tr_fragment(ib + tr_off + 16 * 64);
+        if constexpr (SOFTMAX) {
+            float kv[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kv[j] = (float)at0[j]; kv[8 + j] = (float)at1[j]; }
+            float mt = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (acc_row(r, half) >= nvalid) kv[r] = -1e30f;         // rows past the end weigh nothing
+                mt = fmaxf(mt, kv[r]);
+            }
+            mt = xhalf_max(mt);
+            const float Mn = fmaxf(M, mt);
+            const float corr = __expf(M - Mn);
+            M = Mn;
+            // the sums of feature d live in the registers of row d: the factor goes from lanes to registers through LDS
+            if (half == 0) corr_l[wave][l31] = corr;
+            float zs = 0.f, w[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { w[r] = __expf(kv[r] - Mn); zs += w[r]; }
+            z = z * corr + xhalf_add(zs);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(&corr_l[wave][8 * rg + 4 * half]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * rg + e] *= c4[e];
+            }
+            bf16x8 h0, l0, h1, l1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                h0[j] = f2bf(w[j]);
+                l0[j] = f2bf(w[j] - (float)h0[j]);
+                h1[j] = f2bf(w[8 + j]);
+                l1[j] = f2bf(w[8 + j] - (float)h1[j]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bt0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, bt0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bt1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, bt1, acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at0, bt0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at1, bt1, acc, 0, 0, 0);
+        }
+    }
+    float* out = a.part + (((long long)frame * a.heads + head) * a.nsplit + split) * SR_REC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[acc_row(r, half) * 32 + l31] = acc[r];
+    if (half == 0) { out[1024 + l31] = M; out[1056 + l31] = z; }
+}
+
 int g_sr_enabled = -1;
 
 }   // namespace
+
+// a / b: first and second operand rows (already offset to their columns), as vdmi_sla_train_reduce takes them; the
+// partials have the layout of the vector kernel (sums [32][32], maximum [32], weight sum [32] per split of split_len)
+int vdmi_sla_reduce_mfma_launch(bool softmax, const void* a, int lda, const void* b, int ldb, float* part, int frames, int n,
+                                int heads, int nsplit, int split_len, hipStream_t stream) {
+    SredArgs r{static_cast<const __bf16*>(a), lda, static_cast<const __bf16*>(b), ldb, part, n, heads, nsplit, split_len};
+    const dim3 grid((unsigned)nsplit, (unsigned)((heads + SR_WAVES - 1) / SR_WAVES), (unsigned)frames);
+    if (softmax) hipLaunchKernelGGL(sla_reduce_mfma_kernel<true>, grid, dim3(SR_WAVES * 64), 0, stream, r);
+    else hipLaunchKernelGGL(sla_reduce_mfma_kernel<false>, grid, dim3(SR_WAVES * 64), 0, stream, r);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
 
 extern "C" void vdmi_sla_rows_mfma_enable(int on) { g_sr_enabled = on ? 1 : 0; }
 
