@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const LnArgs a) {
     const int LP = a.c / 8, R = 256 / LP, piece = tid % LP, rslot = tid / LP;
     const int wpr = LP > 64 ? LP / 64 : 1;
     auto row_sum = [&](float v, int slot) -> float {
-        const int lim = LP < 64 ? LP : 64;
-        for (int m = 1; m < lim; m <<= 1) v += __shfl_xor(v, m);
+        // LP is a power of two from 8: the first 16 lanes by DPP, then across DPP rows
+        v = LP >= 16 ? vdmi_row_sum<16>(v) : vdmi_row_sum<8>(v);
+        if (LP >= 32) v += __shfl_xor(v, 16);
+        if (LP >= 64) v = xhalf_add(v);
         if (LP > 64) {
             if (lane == 0) red[slot][wave] = v;
             __syncthreads();

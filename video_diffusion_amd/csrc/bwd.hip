@@ -585,8 +585,10 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_bwd_kernel(const NormBwdArgs
     // sum over the LP consecutive threads of a row (LP a power of two; beyond a wave through LDS)
     const int wpr = LP > 64 ? LP / 64 : 1;           // waves per row
     auto row_sum = [&](float v, float* red) -> float {
-        const int lim = LP < 64 ? LP : 64;
-        for (int m = 1; m < lim; m <<= 1) v += __shfl_xor(v, m);
+        // LP is a power of two from 8: the first 16 lanes by DPP, then across DPP rows
+        v = LP >= 16 ? vdmi_row_sum<16>(v) : vdmi_row_sum<8>(v);
+        if (LP >= 32) v += __shfl_xor(v, 16);
+        if (LP >= 64) v = xhalf_add(v);
         if (LP > 64) {
             if (lane == 0) red[wave] = v;
             __syncthreads();
@@ -626,14 +628,14 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_bwd_kernel(const NormBwdArgs
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += yv[e] * yv[e];
         ss = row_sum(ss, red1);
-        const float inv_r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        const float inv_r = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ss), 1e-12f));
         float du[8], uu[8], dot = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float un = yv[e] * inv_r;
             const float n = un * a.norm_scale * g[e];
             const float z = n * sc1[e] + sh[e];
-            const float sig = 1.0f / (1.0f + __expf(-z));
+            const float sig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
             const float dz = dhv[e] * sig * (1.0f + z * (1.0f - sig));
             a_dsh[e] += dz;
             a_ds[e] += dz * n;

@@ -766,8 +766,10 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const __bf16* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += v[k][e] * v[k][e];
     }
+    // the butterfly over the row's LPR lanes: within 16 lanes by DPP (same pairs, same bits as the shuffles it replaces)
+    ss = vdmi_row_sum<(LPR < 16 ? LPR : 16)>(ss);
 #pragma unroll
-    for (int m = 1; m < LPR; m <<= 1) ss += __shfl_xor(ss, m);
+    for (int m = 16; m < LPR; m <<= 1) ss += __shfl_xor(ss, m);
     const float rinv = norm_scale / fmaxf(sqrtf(ss), 1e-12f);
     const long long b = r / rows_per_batch;
 #pragma unroll

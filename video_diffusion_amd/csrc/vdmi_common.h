@@ -81,6 +81,24 @@ __device__ __forceinline__ float xhalf_max(float v) {
     return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
 }
 
+// Sum over the aligned group of N consecutive lanes (N = 2, 4, 8 or 16), the same value in all of them, with DPP operand
+// modifiers (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) instead of the ds_bpermute round
+// trips of __shfl_xor.  After two steps a quad holds one value, so mirroring within 8 and within 16 lanes pairs the same
+// two partial sums a butterfly with lane ^ 4 / lane ^ 8 would: the result has the same bits.
+template <int CTRL>
+__device__ __forceinline__ float vdmi_dpp(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+template <int N>
+__device__ __forceinline__ float vdmi_row_sum(float v) {
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16, "lanes of one DPP row");
+    if constexpr (N >= 2) v += vdmi_dpp<0xB1>(v);
+    if constexpr (N >= 4) v += vdmi_dpp<0x4E>(v);
+    if constexpr (N >= 8) v += vdmi_dpp<0x141>(v);
+    if constexpr (N >= 16) v += vdmi_dpp<0x140>(v);
+    return v;
+}
+
 // hipFuncSetAttribute acts on the current device only, so "already done" is one bit per device in a mask that each
 // call site keeps for its kernel.  Returns 0 when the kernel may use `bytes` of dynamic LDS on the current device.
 static inline int vdmi_set_max_lds(const void* fn, std::atomic<uint64_t>& done_mask, int bytes) {
