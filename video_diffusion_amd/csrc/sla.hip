@@ -88,8 +88,8 @@ __global__ __launch_bounds__(512, 2) void sla_pass1_kernel(const SlaArgs a) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)pre[k][e]; s1 += f; s2 += f * f; }
-#pragma unroll
-            for (int m = 1; m < PPR; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+            s1 = vdmi_group_sum<PPR>(s1);
+            s2 = vdmi_group_sum<PPR>(s2);
             const float mean = s1 * (1.0f / C);
             const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
             bf16x8 o;

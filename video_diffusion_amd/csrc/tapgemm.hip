@@ -384,8 +384,8 @@ __device__ __forceinline__ void run_pass(const PassDev& g, f32x16 (&acc)[WN / 32
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             float a = s1[k], b = s2[k];
-#pragma unroll
-            for (int m = 1; m < PPR; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+            a = vdmi_group_sum<PPR>(a);
+            b = vdmi_group_sum<PPR>(b);
             const int idx = tid + k * NT;
             if (idx < total && (idx % PPR) == 0) {
                 const float mean = a / ctot;

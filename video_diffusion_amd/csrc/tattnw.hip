@@ -115,8 +115,8 @@ __global__ __launch_bounds__(TW_HEADS * 64) void tattn_wide_kernel(const TWArgs 
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
         }
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        s1 = vdmi_group_sum<8>(s1);
+        s2 = vdmi_group_sum<8>(s2);
         const float mean = s1 * (1.0f / C);
         const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
 #pragma unroll
@@ -476,8 +476,8 @@ __global__ __launch_bounds__(TW_HEADS * 64) void sla_wide_long_kernel(const TWAr
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
         }
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        s1 = vdmi_group_sum<8>(s1);
+        s2 = vdmi_group_sum<8>(s2);
         const float mean = s1 * (1.0f / C);
         const float rstd = rsqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.f) + a.eps);
 #pragma unroll

@@ -99,6 +99,16 @@ __device__ __forceinline__ float vdmi_row_sum(float v) {
     return v;
 }
 
+// The same over an aligned group of N = 2 .. 64 lanes: DPP inside a row of 16, shuffles / the half swap across rows.
+template <int N>
+__device__ __forceinline__ float vdmi_group_sum(float v) {
+    static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "power of two");
+    v = vdmi_row_sum<(N < 16 ? N : 16)>(v);
+    if constexpr (N >= 32) v += __shfl_xor(v, 16);
+    if constexpr (N >= 64) v = xhalf_add(v);
+    return v;
+}
+
 // hipFuncSetAttribute acts on the current device only, so "already done" is one bit per device in a mask that each
 // call site keeps for its kernel.  Returns 0 when the kernel may use `bytes` of dynamic LDS on the current device.
 static inline int vdmi_set_max_lds(const void* fn, std::atomic<uint64_t>& done_mask, int bytes) {
