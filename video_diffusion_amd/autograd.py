@@ -156,8 +156,7 @@ def _temporal_ops(res, x, pos_bias, focus):
 
 def _spatial(res, x):
     # mid_spatial_attn: 'b c f h w -> b f (h w) c', vdp.py:708-710
-    if _HIP_ATTN and x.is_cuda and x.shape[3] * x.shape[4] <= 256 and \
-            _core_fits(x.shape[3] * x.shape[4], res.fn.fn.fn.heads, False):
+    if _HIP_ATTN and x.is_cuda and res.fn.fn.fn.dim_head == 32:
         from .train_hip import spatial_attention      # forward and backward on the HIP kernels
         return spatial_attention(res, x)
     return _torch_ops(lambda x: _spatial_ops(res, x), x)

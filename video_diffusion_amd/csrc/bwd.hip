@@ -18,6 +18,7 @@
 //   The RMSNorm / scale-shift / SiLU backward is a row kernel (two row reductions, per-channel sums by atomics).
 #include "vdmi_common.h"
 
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -719,7 +720,14 @@ extern "C" size_t vdmi_pack_taps_batch_table_bytes(int count) { return count > 0
 extern "C" int vdmi_pack_taps_batch(const vdmi_pack_job* jobs, int count, void* device_table, vdmi_stream stream) {
     if (!jobs || !device_table || count <= 0) return VDMI_E_ARG;
     if (count > 65536) return VDMI_E_SHAPE;
-    std::vector<PackJobDev> tab((size_t)count);
+    // the host copy of the table: a ring of buffers that live on after the call, so that the bytes are still there should
+    // the runtime read a pageable source after hipMemcpyAsync has returned (a buffer is reused eight calls later)
+    static std::mutex ring_mutex;
+    static std::vector<PackJobDev> ring[8];
+    static unsigned ring_next = 0;
+    std::lock_guard<std::mutex> lock(ring_mutex);
+    std::vector<PackJobDev>& tab = ring[ring_next++ & 7u];
+    tab.assign((size_t)count, PackJobDev{});
     long long blocks = 0;
     for (int i = 0; i < count; ++i) {
         const vdmi_pack_job& j = jobs[i];
@@ -741,7 +749,6 @@ extern "C" int vdmi_pack_taps_batch(const vdmi_pack_job* jobs, int count, void* 
     }
     if (blocks <= 0 || blocks > 0x7fffffffLL) return VDMI_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // pageable source: the runtime stages the bytes before the call returns, so `tab` may go out of scope
     if (hipMemcpyAsync(device_table, tab.data(), tab.size() * sizeof(PackJobDev), hipMemcpyHostToDevice, st) != hipSuccess)
         return VDMI_E_LAUNCH;
     hipLaunchKernelGGL(pack_taps_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st,

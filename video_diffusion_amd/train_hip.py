@@ -957,12 +957,20 @@ def attention_core_fits(n_tok: int, heads: int, with_bias: bool) -> bool:
 
 def spatial_attention(res, x: torch.Tensor) -> torch.Tensor:
     """autograd.py's `_spatial` (the mid-block attention over the positions of each frame, vdp.py:708-710: no rotary, no
-    bias) on the HIP kernels; up to 256 positions per frame."""
+    bias) on the HIP kernels."""
     att = res.fn.fn.fn
-    if att.dim_head != 32 or x.shape[3] * x.shape[4] > 256:
-        raise _lib.VdmiError("the HIP spatial attention takes heads of 32 features and frames of at most 256 positions")
-    return TemporalAttnFn.apply(x, res.fn.norm.gamma, att.to_qkv.weight, att.to_out.weight, None, None, None, att.heads,
-                                float(att.scale), float(res.fn.norm.eps), True)
+    if att.dim_head != 32:
+        raise _lib.VdmiError("the HIP spatial attention takes heads of 32 features")
+    b, c, f, h, w = x.shape
+    if h * w <= 32:         # a frame's positions fit one tile of the attention core over short token axes
+        return TemporalAttnFn.apply(x, res.fn.norm.gamma, att.to_qkv.weight, att.to_out.weight, None, None, None, att.heads,
+                                    float(att.scale), float(res.fn.norm.eps), True)
+    # every frame as a sample of its own on the matrix-core self-attention (the cross-attention kernels with the frame's
+    # own rows as context): views only, the rows stay where they are
+    xf = x.transpose(1, 2).reshape(b * f, c, h, w).unsqueeze(2)
+    y = SelfAttnFn.apply(xf, res.fn.norm.gamma, att.to_qkv.weight, att.to_out.weight, att.heads, float(att.scale),
+                         float(res.fn.norm.eps))
+    return y.squeeze(2).reshape(b, f, c, h, w).transpose(1, 2)
 
 
 def temporal_attention(res, x: torch.Tensor, pos_bias, rot_tables, focus=None) -> torch.Tensor:
