@@ -330,7 +330,11 @@ __global__ __launch_bounds__(512, 2) void sla_pass2_kernel(const SlaArgs a) {
                 oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, q1, oacc[ct], 0, 0, 0);
             }
         }
+#ifdef VDMI_SLA_ABL_NOSTORE     // timing-only ablation (wrong results): neither the residual reads nor the stores
+        if (rowvalid && a.eps < -1.f) {
+#else
         if (rowvalid) {
+#endif
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
