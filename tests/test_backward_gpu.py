@@ -579,10 +579,12 @@ def test_bf16_activation_stream_between_hip_layers():
     assert record("stream.focus.param_grads", rel_err(g_hip, g_ref), 5e-2) < 5e-2
 
 
-@pytest.mark.parametrize("rows,cin,cout", [(1000, 64, 64), (777, 72, 40), (64, 128, 384), (40000, 256, 768), (5, 8, 8)])
+@pytest.mark.parametrize("rows,cin,cout", [(1000, 64, 64), (777, 72, 40), (64, 128, 384), (40000, 256, 768), (5, 8, 8),
+                                           (4097, 192, 320), (33, 136, 200), (9000, 128, 128)])
 def test_rows_wgrad_vs_torch(rows, cin, cout):
     """vdmi_rows_wgrad (the weight gradient of a 1x1 convolution / Linear from the rows as they lie, through the transposing
-    LDS read) against dy^T x in float over the same bf16 operands; ragged row counts and channel widths."""
+    LDS read) against dy^T x in float over the same bf16 operands; ragged row counts and channel widths, on the 64 x 64
+    tiles (a width below 128) and on the 128 x 128 tiles (odd numbers of 64-channel tiles, partly empty last tiles)."""
     from tests.helpers import inp
     from video_diffusion_amd import train_hip as T
     x = inp("rw.x", (rows, cin)).to(DEV).to(torch.bfloat16)

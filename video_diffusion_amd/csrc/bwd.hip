@@ -18,6 +18,7 @@
 //   The RMSNorm / scale-shift / SiLU backward is a row kernel (two row reductions, per-channel sums by atomics).
 #include "vdmi_common.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -307,6 +308,111 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const RowsWgradArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         part[((wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + (wave >> 1) * 32 + l31] = acc0[r] + acc1[r];
+}
+
+// The same product with a 128 x 128 tile per workgroup (eight waves: 2 x 2 blocks of 64 x 64 output channels, times two
+// halves of a stage's 64 rows).  A 64 x 64 tile makes the launch read the rows of x once per 64 output channels and the
+// rows of dy once per 64 input channels through L2 - three to six times the operands' size on the layers of a training
+// step, which is what bounds the small tile at ~2.5 TB/s of algorithmic traffic; here it is half of that, every wave
+// has eight MFMAs between two barriers instead of four, and one fragment read per MFMA instead of two.  The two row
+// halves are added through LDS before the partial tiles (the 64 x 64 format of wgrad_reduce_kernel) are written.
+constexpr int RW2_PITCH = 320;          // bytes per LDS row: 128 channels = 256 bytes, + 64
+
+__device__ __forceinline__ bf16x8 lds_tr_fragment2(const char* base) {
+    typedef __attribute__((address_space(3))) s4v* lds_s4;
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base + 4 * RW2_PITCH));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(512) void wgrad_rows128_kernel(const RowsWgradArgs a, int tx, int ty) {
+    __shared__ __attribute__((aligned(16))) char lds[2][2][RW_KC * RW2_PITCH];     // [stage buffer][dy | x]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave & 1, wn = (wave >> 1) & 1, wk = wave >> 2;
+    const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 128;
+    const long long r_begin = (long long)blockIdx.z * a.per;
+    const long long r_end = r_begin + a.per < a.rows ? r_begin + a.per : a.rows;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // staging: piece q = tid + 512 i of a tile is (row q >> 4, channels 8 (q & 15) ..)
+    const int prow = tid >> 4, pc = tid & 15;
+    const bool a_ok = co0 + pc * 8 < a.cout, b_ok = ci0 + pc * 8 < a.cin;
+    bf16x8 va[2], vb[2];
+    auto load = [&](long long r0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long r = r0 + prow + 32 * i;
+            va[i] = (a_ok && r < r_end) ? *reinterpret_cast<const bf16x8*>(a.dy + r * a.lddy + co0 + pc * 8) : zero8;
+            vb[i] = (b_ok && r < r_end) ? *reinterpret_cast<const bf16x8*>(a.x + r * a.ldx + ci0 + pc * 8) : zero8;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<bf16x8*>(&lds[buf][0][(prow + 32 * i) * RW2_PITCH + pc * 16]) = va[i];
+            *reinterpret_cast<bf16x8*>(&lds[buf][1][(prow + 32 * i) * RW2_PITCH + pc * 16]) = vb[i];
+        }
+    };
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int frag_row = 8 * (g >> 1) + q, frag_col = 16 * (g & 1) + 4 * pp;
+    const int a_off = (wk * 32 + frag_row) * RW2_PITCH + (wm * 64 + frag_col) * 2;
+    const int b_off = (wk * 32 + frag_row) * RW2_PITCH + (wn * 64 + frag_col) * 2;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int cur = 0;
+    if (r_begin < r_end) {
+        load(r_begin);
+        store(0);
+        __syncthreads();
+        for (long long r0 = r_begin; r0 < r_end; r0 += RW_KC) {
+            const bool more = r0 + RW_KC < r_end;
+            if (more) load(r0 + RW_KC);
+            const char* ta = &lds[cur][0][a_off];
+            const char* tb = &lds[cur][1][b_off];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {              // this wave's two k-steps (16 rows each) of the stage
+                const bf16x8 A0 = lds_tr_fragment2(ta + ks * 16 * RW2_PITCH), A1 = lds_tr_fragment2(ta + ks * 16 * RW2_PITCH + 64);
+                const bf16x8 B0 = lds_tr_fragment2(tb + ks * 16 * RW2_PITCH), B1 = lds_tr_fragment2(tb + ks * 16 * RW2_PITCH + 64);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[1][1], 0, 0, 0);
+            }
+            if (more) store(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // the second row half hands its sums to the first through LDS (64 KiB of the stage buffers), which writes the tiles
+    float* xch = reinterpret_cast<float*>(&lds[0][0][0]) + (wm + 2 * wn) * 4096;
+    __syncthreads();
+    if (wk == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[((i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+        const int t_x = blockIdx.x * 2 + wm, t_y = blockIdx.y * 2 + wn;       // this wave's 64 x 64 tile
+        if (t_x < tx && t_y < ty) {
+            float* part = a.part + ((size_t)blockIdx.z * ((size_t)tx * ty) + (size_t)t_y * tx + t_x) * 4096;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        part[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] =
+                            acc[i][j][r] + xch[((i * 2 + j) * 16 + r) * 64 + lane];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -871,14 +977,21 @@ extern "C" int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int c
 }
 
 namespace {
-struct RowsWgradPlan { int tx, ty; long long per, gz; };
+int g_rw128 = -1;        // the 128 x 128 tile: on unless VDMI_WGRAD_ROWS128=0
+struct RowsWgradPlan { int tx, ty; long long per, gz; bool big; };
 int rows_wgrad_plan(int cin, int cout, int64_t rows, RowsWgradPlan* p) {
     if (cin <= 0 || cout <= 0 || cin % 8 || cout % 8 || rows <= 0) return VDMI_E_SHAPE;
+    if (g_rw128 < 0) {
+        const char* e = std::getenv("VDMI_WGRAD_ROWS128");
+        g_rw128 = (e && e[0] == '0') ? 0 : 1;
+    }
     p->tx = (cout + 63) / 64;
     p->ty = (cin + 63) / 64;
     if (p->tx > 65535 || p->ty > 65535) return VDMI_E_SHAPE;
-    const long long tiles = (long long)p->tx * p->ty;
-    long long split = (768 + tiles - 1) / tiles;          // ~3 workgroups per CU (48 KB of LDS each)
+    p->big = g_rw128 && cin >= 128 && cout >= 128;
+    const long long tiles = p->big ? (long long)((p->tx + 1) / 2) * ((p->ty + 1) / 2) : (long long)p->tx * p->ty;
+    // small tile: ~3 workgroups per CU (48 KB of LDS each); big tile: two per CU (80 KB each)
+    long long split = ((p->big ? 512 : 768) + tiles - 1) / tiles;
     const long long stages = (rows + RW_KC - 1) / RW_KC;
     if (split > stages) split = stages;
     p->per = (stages + split - 1) / split * RW_KC;
@@ -907,7 +1020,11 @@ extern "C" int vdmi_rows_wgrad(const void* x, int ldx, const void* dy, int lddy,
     a.dy = static_cast<const __bf16*>(dy); a.lddy = lddy;
     a.part = static_cast<float*>(workspace);
     a.cin = cin; a.cout = cout; a.rows = rows; a.per = p.per;
-    hipLaunchKernelGGL(wgrad_rows_kernel, dim3((unsigned)p.tx, (unsigned)p.ty, (unsigned)p.gz), dim3(256), 0, s, a);
+    if (p.big)
+        hipLaunchKernelGGL(wgrad_rows128_kernel, dim3((unsigned)((p.tx + 1) / 2), (unsigned)((p.ty + 1) / 2), (unsigned)p.gz),
+                           dim3(512), 0, s, a, p.tx, p.ty);
+    else
+        hipLaunchKernelGGL(wgrad_rows_kernel, dim3((unsigned)p.tx, (unsigned)p.ty, (unsigned)p.gz), dim3(256), 0, s, a);
     VDMI_LAUNCH_CHECK();
     const long long elems = (long long)p.tx * p.ty * 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, a.part, (int)p.gz, p.tx,
