@@ -990,8 +990,15 @@ int rows_wgrad_plan(int cin, int cout, int64_t rows, RowsWgradPlan* p) {
     if (p->tx > 65535 || p->ty > 65535) return VDMI_E_SHAPE;
     p->big = g_rw128 && cin >= 128 && cout >= 128;
     const long long tiles = p->big ? (long long)((p->tx + 1) / 2) * ((p->ty + 1) / 2) : (long long)p->tx * p->ty;
-    // small tile: ~3 workgroups per CU (48 KB of LDS each); big tile: two per CU (80 KB each)
-    long long split = ((p->big ? 512 : 768) + tiles - 1) / tiles;
+    // small tile: ~3 workgroups per CU (48 KB of LDS each); big tile: one and a half rounds of one per CU (fewer, longer
+    // workgroups also mean fewer partial tiles for the reduce launch)
+    static int big_wgs = 0;
+    if (!big_wgs) {
+        const char* e = std::getenv("VDMI_WGRAD_ROWS128_WGS");
+        big_wgs = e ? std::atoi(e) : 384;       // measured over the training step: 256 / 384 / 512 / 768 -> 30.15 / 29.96 / 30.39 / 30.6 ms
+        if (big_wgs < 64 || big_wgs > 4096) big_wgs = 384;
+    }
+    long long split = ((p->big ? big_wgs : 768) + tiles - 1) / tiles;
     const long long stages = (rows + RW_KC - 1) / RW_KC;
     if (split > stages) split = stages;
     p->per = (stages + split - 1) / split * RW_KC;
