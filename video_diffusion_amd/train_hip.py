@@ -222,6 +222,8 @@ class PackStore:
             e.age += 1
         if not stale:
             return
+        # the forward and the input-gradient set of a weight next to each other: the second reads the weight from cache
+        stale.sort(key=lambda e: e.weight.data_ptr())
         self._table = pack_batch([j for e in stale for j in self._jobs(e)], stale[0].weight.device)
         for e in stale:
             self._stamp(e)
