@@ -344,3 +344,27 @@ def test_guidance_variant_reconstruction_guidance_on_the_gpu():
     x = gd.p_sample(zd, td, guidance_fn=GV.temporal_consistency_guidance(gd, prev.to(dev), 2, w_r=3.0), guidance_scale=1.0,
                     noise=torch.zeros_like(zd))
     assert x.shape == zd.shape and bool(torch.isfinite(x).all())
+
+
+def test_resample_gather_tables_reproduce_the_rearranged_kernels():
+    """train_hip._resample_gathers: the index tables the weight packer gathers through give, applied to the flattened
+    parameter, exactly the re-arranged kernels written out with torch ops - the 2x2 / stride-1 kernel over the
+    space-to-depth view for Downsample's Conv3d(1,4,4) (reference vdp.py:377-378) and the four per-parity tap sets of
+    Upsample's ConvTranspose3d (vdp.py:374-375)."""
+    from video_diffusion_amd import train_hip as T
+    g = torch.Generator().manual_seed(5)
+    n, cin = 6, 4
+    w = torch.randn(n, cin, 1, 4, 4, generator=g)                      # Conv3d weight (out, in, 1, 4, 4)
+    (tab,) = T._resample_gathers("down", w)
+    w4 = w[:, :, 0]
+    ref = torch.cat([torch.stack([w4[:, :, 2 * dy + a, 2 * dx + b] for dy in (0, 1) for dx in (0, 1)], dim=-1)
+                     for a in (0, 1) for b in (0, 1)], dim=1)
+    assert tab.dtype == torch.int32 and tab.shape == (n, 4 * cin, 4)
+    assert torch.equal(w.flatten()[tab.long()], ref)
+    wt = torch.randn(cin, n, 1, 4, 4, generator=g)                     # ConvTranspose3d weight (in, out, 1, 4, 4)
+    tabs = T._resample_gathers("up", wt)
+    w4 = wt[:, :, 0]
+    assert len(tabs) == 4
+    for tab, (pp, q) in zip(tabs, [(pp, q) for pp in (0, 1) for q in (0, 1)]):
+        ref = torch.stack([w4[:, :, ky, kx].t() for (ky, _) in T._UP_PAIRS[pp] for (kx, _) in T._UP_PAIRS[q]], dim=-1)
+        assert tab.shape == (n, cin, 4) and torch.equal(wt.flatten()[tab.long()], ref)
