@@ -161,11 +161,22 @@ def train_step(args, dev):
         runs = tuple(r for r in runs if r[0].split()[0] in args.train_backends.split(","))
     if args.train_amp_only:
         runs = tuple(r for r in runs if r[2])
+    opt = torch.optim.Adam(unet.parameters(), lr=1e-5, fused=True)
+
+    def full_step(backend, amp):
+        # what a Trainer iteration runs: forward + backward, then the (fused) optimizer step; the next forward then finds
+        # every packed weight set stale (step() invalidates the store itself, as the Trainer does after opt.step())
+        step(backend, amp)
+        opt.step()
+
     for name, backend, amp in runs:
         torch.cuda.reset_peak_memory_stats()
         try:
             ms = timed(lambda: step(backend, amp), args.train_steps, warmup=1)
             out["ms_per_step"][name] = round(ms, 2)
+            if args.train_with_adam:
+                out.setdefault("ms_per_step_with_fused_adam", {})[name] = round(
+                    timed(lambda: full_step(backend, amp), args.train_steps, warmup=1), 2)
             out["loss"][name] = round(float(step(backend, amp)), 5)
             out["peak_mem_gib"][name] = round(torch.cuda.max_memory_allocated() / 2**30, 2)
         except Exception as e:     # report, do not hide: a backend that cannot run this shape says why
@@ -233,6 +244,7 @@ def main():
     ap.add_argument("--train-dim", type=int, default=128)
     ap.add_argument("--train-frames", type=int, default=16)
     ap.add_argument("--train-amp-only", action="store_true", help="skip the runs whose torch layers compute in fp32")
+    ap.add_argument("--train-with-adam", action="store_true", help="also time the step followed by a fused Adam update")
     ap.add_argument("--train-context", type=int, default=0, help="context tokens of previous-frame conditioning (0: none)")
     ap.add_argument("--train-channels", type=int, default=3)
     ap.add_argument("--train-steps", type=int, default=3)
