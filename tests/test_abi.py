@@ -241,3 +241,23 @@ def test_attention_core_fit_query():
     assert lib.vdmi_tattn_core_fits(1, 10, 8, 1) == 1 and lib.vdmi_tattn_core_fits(1, 32, 8, 1) == 1
     assert lib.vdmi_tattn_core_fits(1, 64, 8, 1) == 0 and lib.vdmi_tattn_core_fits(0, 64, 8, 0) == 1
     assert lib.vdmi_tattn_core_fits(0, 257, 8, 0) == 0 and lib.vdmi_tattn_core_fits(1, 0, 8, 0) == 0
+
+
+def test_batched_weight_packer_rejects_bad_arguments():
+    """vdmi_pack_taps_batch checks its job table on the host before anything is copied or launched."""
+    import ctypes as C
+    from video_diffusion_amd import _lib
+    lib = _lib.lib()
+    E_ARG, E_SHAPE, E_ALIGN = -1, -2, -3
+    assert lib.vdmi_pack_taps_batch_table_bytes(3) == 3 * 80 and lib.vdmi_pack_taps_batch_table_bytes(0) == 0
+    ok = _lib.PackJob(16, None, None, 16, 64, 64, 64, 0, 9, 64, 0)
+    arr = (_lib.PackJob * 1)(ok)
+    assert lib.vdmi_pack_taps_batch(None, 1, 16, None) == E_ARG
+    assert lib.vdmi_pack_taps_batch(C.cast(arr, C.c_void_p), 0, 16, None) == E_ARG
+    assert lib.vdmi_pack_taps_batch(C.cast(arr, C.c_void_p), 1, None, None) == E_ARG
+    for field, value, status in (("w", None, E_ARG), ("out", None, E_ARG), ("out", 24, E_ALIGN), ("npad", 48, E_SHAPE),
+                                 ("bkc", 48, E_SHAPE), ("ntaps", 0, E_SHAPE), ("cin0", 0, E_SHAPE)):
+        bad = _lib.PackJob(16, None, None, 16, 64, 64, 64, 0, 9, 64, 0)
+        setattr(bad, field, value)
+        arr = (_lib.PackJob * 2)(ok, bad)
+        assert lib.vdmi_pack_taps_batch(C.cast(arr, C.c_void_p), 2, 16, None) == status, field
