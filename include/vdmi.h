@@ -533,6 +533,16 @@ int vdmi_rmsnorm_silu_bwd(const void* y, int ldy, const void* dh, int ldh, void*
                           int64_t sstride, float norm_scale, float* dgamma, float* dbias, float* dscale, float* dshift,
                           vdmi_stream stream);
 
+/* The same gradients without float atomics: every workgroup leaves its four per-channel sums in `workspace`
+ * (vdmi_rmsnorm_silu_bwd_workspace_bytes() bytes, 16-byte aligned; 0 for a shape the kernel does not take) and a second
+ * launch adds them in a fixed order, so dgamma, dbias, dscale and dshift are WRITTEN (no zero fill needed) and are the
+ * same bits on every run.  All other arguments as above. */
+size_t vdmi_rmsnorm_silu_bwd_workspace_bytes(int batch, int64_t rows_per_batch, int c);   /* HOST */
+int vdmi_rmsnorm_silu_bwd_ws(const void* y, int ldy, const void* dh, int ldh, void* dy, int lddy, int batch,
+                             int64_t rows_per_batch, int c, const float* gamma, const float* scale, const float* shift,
+                             int64_t sstride, float norm_scale, float* dgamma, float* dbias, float* dscale, float* dshift,
+                             void* workspace, vdmi_stream stream);
+
 /* out[ch] += sum over rows of x[row][ch]  (bias gradient of res_conv, vdp.py:439); x bf16 [rows][ld], c <= 2048. */
 int vdmi_colsum(const void* x, int ld, int64_t rows, int c, float* out, vdmi_stream stream);
 

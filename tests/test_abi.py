@@ -202,6 +202,17 @@ def test_backward_entry_points_reject_bad_arguments():
                                      None) == E_SHAPE                                                   # c not a power of two
     assert lib.vdmi_rmsnorm_silu_bwd(16, 64, 16, 64, 16, 64, 1, 10, 64, 16, 16, None, 64, 8.0, 16, None, None, None,
                                      None) == E_ARG                                                     # scale without shift
+    # the form that adds per-workgroup partials in a fixed order: one partial [4][c] per 16 passes of 256 / (c / 8) rows
+    assert lib.vdmi_rmsnorm_silu_bwd_workspace_bytes(2, 1000, 64) == 2 * ((1000 + 511) // 512) * 4 * 64 * 4
+    assert lib.vdmi_rmsnorm_silu_bwd_workspace_bytes(1, 1, 2048) == 4 * 2048 * 4
+    assert lib.vdmi_rmsnorm_silu_bwd_workspace_bytes(1, 10, 96) == 0
+    assert lib.vdmi_rmsnorm_silu_bwd_workspace_bytes(0, 10, 64) == 0
+    assert lib.vdmi_rmsnorm_silu_bwd_ws(16, 64, 16, 64, 16, 64, 1, 10, 64, 16, None, None, 0, 8.0, 16, None, None, None,
+                                        None, None) == E_ARG                                            # no workspace
+    assert lib.vdmi_rmsnorm_silu_bwd_ws(16, 64, 16, 64, 16, 64, 1, 10, 64, 16, None, None, 0, 8.0, 16, None, None, None,
+                                        8, None) == E_ALIGN
+    assert lib.vdmi_rmsnorm_silu_bwd_ws(16, 96, 16, 96, 16, 96, 1, 10, 96, 16, None, None, 0, 9.8, 16, None, None, None,
+                                        16, None) == E_SHAPE
     assert lib.vdmi_colsum(None, 64, 10, 64, None, None) == E_ARG
     assert lib.vdmi_colsum(16, 64, 10, 4096, 16, None) == E_SHAPE
 

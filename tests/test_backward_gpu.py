@@ -126,9 +126,12 @@ def _norm_ref(y, gamma, scale, shift):
     return F.silu(n)
 
 
-@pytest.mark.parametrize("c,batch,rpb,with_ss", [(64, 2, 1000, True), (256, 3, 77, True), (1024, 2, 130, False), (128, 1, 5000, True)])
-def test_rmsnorm_silu_bwd_vs_torch(c, batch, rpb, with_ss):
+@pytest.mark.parametrize("form", ["fixed_order", "atomic"])
+@pytest.mark.parametrize("c,batch,rpb,with_ss", [(64, 2, 1000, True), (256, 3, 77, True), (1024, 2, 130, False), (128, 1, 5000, True),
+                                                 (2048, 2, 37, True), (512, 1, 1, False), (128, 4, 16 * 24 * 24, True)])
+def test_rmsnorm_silu_bwd_vs_torch(c, batch, rpb, with_ss, form, monkeypatch):
     from video_diffusion_amd import train_hip as T
+    monkeypatch.setattr(T, "_NORM_BWD_FIXED_ORDER", form == "fixed_order")
     g = torch.Generator().manual_seed(4)
     y = _bf(torch.randn(batch * rpb, c, generator=g) * 1.5).to(DEV)
     dh = _bf(torch.randn(batch * rpb, c, generator=g)).to(DEV)
@@ -143,7 +146,12 @@ def test_rmsnorm_silu_bwd_vs_torch(c, batch, rpb, with_ss):
     rows_scale = sr.repeat_interleave(rpb, dim=0) if with_ss else None
     rows_shift = hr.repeat_interleave(rpb, dim=0) if with_ss else None
     _norm_ref(yr, gr, rows_scale, rows_shift).backward(dh.double())
-    tag = f"normbwd.c{c}"
+    if form == "fixed_order":
+        # no float atomics in this form: a second call gives the same bits
+        again = T.rmsnorm_silu_bwd_rows(y, dh, gamma, scale, shift, batch, rpb)
+        for first, second in zip((dy, dgamma, dbias, dscale, dshift), again):
+            assert first is None or torch.equal(first, second)
+    tag = f"normbwd.{form}.c{c}"
     assert record(tag + ".dy", rel_err(dy.float().cpu(), yr.grad.cpu()), 1e-2) < 1e-2          # bf16 output
     assert record(tag + ".dgamma", rel_err(dgamma.cpu(), gr.grad.cpu()), 2e-3) < 2e-3
     assert record(tag + ".dbias", rel_err(dbias.cpu(), yr.grad.sum(0).cpu()), 2e-3) < 2e-3

@@ -183,6 +183,10 @@ _SIGNATURES = {
     "vdmi_rmsnorm_silu_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64,
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdmi_rmsnorm_silu_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
+    "vdmi_rmsnorm_silu_bwd_ws": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float] +
+                                 [C.c_void_p] * 6),
     "vdmi_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "vdmi_layernorm_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "vdmi_layernorm_rows_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_float, C.c_void_p]),

@@ -666,6 +666,7 @@ struct NormBwdArgs {
     int c;
     float norm_scale;
     long long rows_per_chunk;
+    float* part;                 // [b][chunk][4][c] per-workgroup sums (then nothing is added to dgamma .. dshift), or null
 };
 
 __global__ __launch_bounds__(256) void rmsnorm_silu_bwd_kernel(const NormBwdArgs a) {
@@ -763,6 +764,26 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_bwd_kernel(const NormBwdArgs
         if (valid) *reinterpret_cast<bf16x8*>(a.dy + row * a.lddy + ch) = o;
     }
     __syncthreads();
+    if (a.part) {
+        // no atomics: every row slot leaves its sums in LDS ([slot][4][c], 32 KiB whatever c), one thread per (sum,
+        // channel) adds the slots in order and writes the workgroup's partial; a second launch adds the partials in order
+        float* tile = colred;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            tile[(rslot * 4 + 0) * a.c + ch + e] = a_dg[e];
+            tile[(rslot * 4 + 1) * a.c + ch + e] = a_db[e];
+            tile[(rslot * 4 + 2) * a.c + ch + e] = a_ds[e];
+            tile[(rslot * 4 + 3) * a.c + ch + e] = a_dsh[e];
+        }
+        __syncthreads();
+        float* out = a.part + ((size_t)b * gridDim.x + blockIdx.x) * 4 * a.c;
+        for (int i = tid; i < 4 * a.c; i += 256) {
+            float sum = 0.f;
+            for (int rs = 0; rs < R; ++rs) sum += tile[rs * 4 * a.c + i];
+            out[i] = sum;
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         atomicAdd(&colred[0 * a.c + ch + e], a_dg[e]);
@@ -800,6 +821,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
         for (int e = 0; e < 8; ++e) atomicAdd(&colred[piece * 8 + e], s[e]);
     __syncthreads();
     for (int i = tid; i < c; i += 256) unsafeAtomicAdd(out + i, colred[i]);
+}
+
+// dgamma[i], dbias[i] = sum over samples and chunks, dscale[b][i], dshift[b][i] = sum over chunks of the per-workgroup
+// partials [b][chunk][4][c] of rmsnorm_silu_bwd_kernel, in a fixed order: a workgroup takes 32 channels of one output
+// row (q = 0: dgamma, 1: dbias, 2 + b: dscale[b], 2 + batch + b: dshift[b]), 32 interleaved chains of chunks each
+__global__ __launch_bounds__(1024) void norm_bwd_reduce_kernel(const float* __restrict__ part, int chunks, int batch, int c,
+                                                               float* dgamma, float* dbias, float* dscale, float* dshift) {
+    __shared__ float red[32][33];
+    const int q = blockIdx.y, i = blockIdx.x * 32 + (threadIdx.x & 31), chain = threadIdx.x >> 5;
+    const int which = q == 0 ? 0 : (q == 1 ? 1 : (q < 2 + batch ? 2 : 3));
+    const int b_begin = q < 2 ? 0 : (q < 2 + batch ? q - 2 : q - 2 - batch), b_end = q < 2 ? batch : b_begin + 1;
+    float s = 0.f;
+    if (i < c) {
+        for (int b = b_begin; b < b_end; ++b) {
+            const float* p = part + ((size_t)b * chunks * 4 + which) * c + i;
+#pragma unroll 8
+            for (int k = chain; k < chunks; k += 32) s += p[(size_t)k * 4 * c];
+        }
+    }
+    red[chain][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (chain == 0 && i < c) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
+        float* dst = q == 0 ? dgamma : (q == 1 ? dbias : (q < 2 + batch ? dscale + (size_t)(q - 2) * c
+                                                                           : dshift + (size_t)(q - 2 - batch) * c));
+        if (dst) dst[i] = t;
+    }
 }
 
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -1071,10 +1121,18 @@ extern "C" int vdmi_conv_wgrad_gather(const void* xT, const void* dyT, float* dw
     return VDMI_OK;
 }
 
-extern "C" int vdmi_rmsnorm_silu_bwd(const void* y, int ldy, const void* dh, int ldh, void* dy, int lddy, int batch,
-                                     int64_t rows_per_batch, int c, const float* gamma, const float* scale,
-                                     const float* shift, int64_t sstride, float norm_scale, float* dgamma, float* dbias,
-                                     float* dscale, float* dshift, vdmi_stream stream) {
+namespace {
+long long norm_bwd_chunks(int64_t rows_per_batch, int c) {
+    const int R = 256 / (c / 8);
+    const long long per = (long long)R * 16;
+    return (rows_per_batch + per - 1) / per;
+}
+}   // namespace
+
+static int rmsnorm_silu_bwd_impl(const void* y, int ldy, const void* dh, int ldh, void* dy, int lddy, int batch,
+                                 int64_t rows_per_batch, int c, const float* gamma, const float* scale,
+                                 const float* shift, int64_t sstride, float norm_scale, float* dgamma, float* dbias,
+                                 float* dscale, float* dshift, void* workspace, vdmi_stream stream) {
     if (!y || !dh || !dy || !gamma || !dgamma) return VDMI_E_ARG;
     if ((scale == nullptr) != (shift == nullptr)) return VDMI_E_ARG;
     if ((dscale || dshift) && !scale) return VDMI_E_ARG;
@@ -1091,16 +1149,46 @@ extern "C" int vdmi_rmsnorm_silu_bwd(const void* y, int ldy, const void* dh, int
     a.rows_per_batch = rows_per_batch; a.c = c; a.norm_scale = norm_scale;
     const int R = 256 / (c / 8);
     // 16 passes per workgroup: a pass is one load - reduce - reduce - store chain, and only other workgroups on the CU
-    // cover its latency (64 passes: 130 us per layer at 16 x 128 x 128, 16 passes: 65 us); the price is one atomic per
-    // channel and workgroup
-    long long per = (long long)R * 16;
-    long long chunks = (rows_per_batch + per - 1) / per;
+    // cover its latency (64 passes: 130 us per layer at 16 x 128 x 128, 16 passes: 65 us; 8 / 4 / 2 passes cost the
+    // training step +0.4 / +1.9 / +4.8 ms when the sums went to float atomics on the same few addresses)
+    const long long per = (long long)R * 16;
+    const long long chunks = norm_bwd_chunks(rows_per_batch, c);
     if (chunks > 0x7fffffffLL) return VDMI_E_SHAPE;
     a.rows_per_chunk = per;
-    hipLaunchKernelGGL(rmsnorm_silu_bwd_kernel, dim3((unsigned)chunks, (unsigned)batch), dim3(256),
-                       (size_t)4 * c * sizeof(float), static_cast<hipStream_t>(stream), a);
+    a.part = static_cast<float*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = workspace ? (size_t)R * 4 * c * sizeof(float) : (size_t)4 * c * sizeof(float);
+    hipLaunchKernelGGL(rmsnorm_silu_bwd_kernel, dim3((unsigned)chunks, (unsigned)batch), dim3(256), lds, st, a);
     VDMI_LAUNCH_CHECK();
+    if (workspace) {
+        const int nq = 2 + (dscale || dshift ? 2 * batch : 0);
+        hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)((c + 31) / 32), (unsigned)nq), dim3(1024), 0, st,
+                           a.part, (int)chunks, batch, c, dgamma, dbias, dscale, dshift);
+        VDMI_LAUNCH_CHECK();
+    }
     return VDMI_OK;
+}
+
+extern "C" int vdmi_rmsnorm_silu_bwd(const void* y, int ldy, const void* dh, int ldh, void* dy, int lddy, int batch,
+                                     int64_t rows_per_batch, int c, const float* gamma, const float* scale,
+                                     const float* shift, int64_t sstride, float norm_scale, float* dgamma, float* dbias,
+                                     float* dscale, float* dshift, vdmi_stream stream) {
+    return rmsnorm_silu_bwd_impl(y, ldy, dh, ldh, dy, lddy, batch, rows_per_batch, c, gamma, scale, shift, sstride, norm_scale,
+                                 dgamma, dbias, dscale, dshift, nullptr, stream);
+}
+
+extern "C" size_t vdmi_rmsnorm_silu_bwd_workspace_bytes(int batch, int64_t rows_per_batch, int c) {
+    if (batch <= 0 || rows_per_batch <= 0 || c < 64 || c > 2048 || (c & (c - 1))) return 0;
+    return (size_t)batch * (size_t)norm_bwd_chunks(rows_per_batch, c) * 4 * c * sizeof(float);
+}
+
+extern "C" int vdmi_rmsnorm_silu_bwd_ws(const void* y, int ldy, const void* dh, int ldh, void* dy, int lddy, int batch,
+                                        int64_t rows_per_batch, int c, const float* gamma, const float* scale,
+                                        const float* shift, int64_t sstride, float norm_scale, float* dgamma, float* dbias,
+                                        float* dscale, float* dshift, void* workspace, vdmi_stream stream) {
+    if (!workspace || !aligned16(workspace)) return workspace ? VDMI_E_ALIGN : VDMI_E_ARG;
+    return rmsnorm_silu_bwd_impl(y, ldy, dh, ldh, dy, lddy, batch, rows_per_batch, c, gamma, scale, shift, sstride, norm_scale,
+                                 dgamma, dbias, dscale, dshift, workspace, stream);
 }
 
 extern "C" int vdmi_colsum(const void* x, int ld, int64_t rows, int c, float* out, vdmi_stream stream) {

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 
 import torch
 import torch.nn.functional as F
@@ -392,22 +393,34 @@ def conv_wgrad_gather(x_t, dy_t, cin, cout, nf, h, w, kh, kw) -> torch.Tensor:
     return dw
 
 
+# VDMI_NORM_BWD_ATOMIC=1: the gradient sums of Block's norm through float atomics (A/B switch; the default adds
+# per-workgroup partials in a fixed order)
+_NORM_BWD_FIXED_ORDER = os.environ.get("VDMI_NORM_BWD_ATOMIC", "0") != "1"
+
+
 def rmsnorm_silu_bwd_rows(y, dh, gamma, scale, shift, batch, rows_per_batch, want_bias=True):
     rows, c = y.shape
     dev = y.device
     dy = torch.empty_like(y)
-    # the kernel accumulates into all four: one zero fill, four views
     nb = batch if scale is not None else 0
-    acc = torch.zeros(2 + 2 * nb, c, device=dev, dtype=torch.float32)
+    lib = _lib.lib()
+    ptr = lambda t: None if t is None else t.data_ptr()
+    args = lambda: (y.data_ptr(), c, dh.data_ptr(), dh.shape[1], dy.data_ptr(), c, batch, rows_per_batch, c,
+                    gamma.data_ptr(), ptr(scale), ptr(shift), c, float(c) ** 0.5, dgamma.data_ptr(), ptr(dbias),
+                    ptr(dscale), ptr(dshift))
+    ws_bytes = lib.vdmi_rmsnorm_silu_bwd_workspace_bytes(batch, rows_per_batch, c) if _NORM_BWD_FIXED_ORDER else 0
+    # fixed-order form: the sums are written, from per-workgroup partials in a workspace; the other form accumulates
+    # into all four with float atomics: one zero fill, four views
+    acc = (torch.empty if ws_bytes else torch.zeros)(2 + 2 * nb, c, device=dev, dtype=torch.float32)
     dgamma = acc[0]
     dbias = acc[1] if want_bias else None
     dscale = acc[2:2 + nb] if scale is not None else None
     dshift = acc[2 + nb:] if scale is not None else None
-    ptr = lambda t: None if t is None else t.data_ptr()
-    check(_lib.lib().vdmi_rmsnorm_silu_bwd(
-        y.data_ptr(), c, dh.data_ptr(), dh.shape[1], dy.data_ptr(), c, batch, rows_per_batch, c, gamma.data_ptr(),
-        ptr(scale), ptr(shift), c, float(c) ** 0.5, dgamma.data_ptr(), ptr(dbias), ptr(dscale), ptr(dshift), _stream()),
-        "vdmi_rmsnorm_silu_bwd")
+    if ws_bytes:
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        check(lib.vdmi_rmsnorm_silu_bwd_ws(*args(), ws.data_ptr(), _stream()), "vdmi_rmsnorm_silu_bwd_ws")
+    else:
+        check(lib.vdmi_rmsnorm_silu_bwd(*args(), _stream()), "vdmi_rmsnorm_silu_bwd")
     return dy, dgamma, dbias, dscale, dshift
 
 
@@ -684,7 +697,6 @@ def _linear_pack(w2: torch.Tensor, transposed: bool, in_scale=None) -> DevPack:
     # tiles the 3x3 convolutions of the wide levels take: a row GEMM is bound by its rows' traffic, and every channel
     # tile of a workgroup column reads the input rows again (measured over the training step: 31.1 -> 30.6 ms;
     # VDMI_LINEAR_TILE_BELOW=0 brings the 64-channel tiles back for an A/B)
-    import os
     thr = int(os.environ.get("VDMI_LINEAR_TILE_BELOW", str(1 << 30)))
     tile = 0 if min(w2.shape[0], w2.shape[1]) <= thr else None
     return param_pack(w2.reshape(w2.shape[0], w2.shape[1], 1, 1, 1), transposed, tile, in_scale)
