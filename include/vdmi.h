@@ -514,6 +514,15 @@ size_t vdmi_rows_wgrad_workspace_bytes(int cin, int cout, int64_t rows);        
 int vdmi_rows_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, int cin, int cout, int cin_total,
                     int cin_off, int64_t rows, void* workspace, vdmi_stream stream);
 
+/* The (1,3,3) weight gradient straight from the channels-last rows, without transposed copies: x [nf*h*w][ldx] (the
+ * convolution's input rows, cin channels from column 0), dy [nf*h*w][lddy] (gradient of its output rows), both bf16;
+ * dw float [cout][cin_total][3][3], written at input channels cin_off .. cin_off + cin (not accumulated).  cin, cout,
+ * ldx, lddy multiples of 8.  workspace: vdmi_conv_wgrad_rows_workspace_bytes() bytes (0: shape not taken).
+ * Replaces the weight-gradient half of F.conv3d's backward for Block.project (vdp.py:387, 391-398). */
+size_t vdmi_conv_wgrad_rows_workspace_bytes(int cin, int cout, int nf, int h, int w);   /* HOST */
+int vdmi_conv_wgrad_rows(const void* x, int ldx, const void* dy, int lddy, float* dw, int cin, int cout, int cin_total,
+                         int cin_off, int nf, int h, int w, void* workspace, vdmi_stream stream);
+
 /* The same gradient for a (1,kh,kw) "same" convolution with few input channels (Unet3D.init_conv, vdp.py:644: 3 -> dim,
  * 7 x 7): a column of the contraction is a (ci, ky, kx) triple, so no lane idles on padding channels.  kh, kw odd;
  * dw float [cout][cin][kh][kw], written (not accumulated); workspace: vdmi_conv_wgrad_gather_workspace_bytes() bytes. */

@@ -79,6 +79,28 @@ def test_conv_wgrad_vs_torch(nf, h, w, cin, cout, ntaps):
     assert err < 1e-3
 
 
+@pytest.mark.parametrize("nf,h,w,cin,cout", [(10, 8, 8, 64, 64), (20, 12, 10, 72, 40), (3, 16, 16, 128, 64), (33, 5, 7, 8, 32),
+                                             (2, 37, 45, 64, 136), (3, 64, 64, 128, 128), (16, 16, 16, 256, 192), (1, 1, 1, 8, 8),
+                                             (2, 128, 128, 64, 64), (5, 4, 33, 24, 16)])
+def test_conv_wgrad_rows_vs_torch(nf, h, w, cin, cout):
+    """vdmi_conv_wgrad_rows (no transposed copies): both tile shapes (w <= 16 and wider), ragged widths / heights / channel
+    counts, more workgroups than units, and the transposed-operand form as a second reference."""
+    from video_diffusion_amd import train_hip as T
+    g = torch.Generator().manual_seed(3)
+    x = _bf(torch.randn(nf * h * w, cin, generator=g)).to(DEV)
+    dy = _bf(torch.randn(nf * h * w, cout, generator=g)).to(DEV)
+    assert T._WGRAD3_ROWS
+    dw = T.conv3x3_wgrad(x, dy, nf, h, w)
+    xi = x.float().view(nf, h, w, cin).permute(0, 3, 1, 2)
+    gi = dy.float().view(nf, h, w, cout).permute(0, 3, 1, 2)
+    wt = torch.zeros(cout, cin, 3, 3, device=DEV, requires_grad=True)
+    F.conv2d(xi.double(), wt.double(), padding=1).backward(gi.double())
+    err = record(f"wgrad_rows.nf{nf}.{h}x{w}.{cin}to{cout}", rel_err(dw.view(cout, cin, 3, 3).cpu(), wt.grad.cpu()), 1e-3)
+    assert err < 1e-3
+    old = T.conv_wgrad(T.rows_transposed(x, nf, h * w), T.rows_transposed(dy, nf, h * w), cin, cout, nf, h, w, 9)
+    assert rel_err(dw.cpu(), old.cpu()) < 1e-4
+
+
 @pytest.mark.parametrize("b,f,h,w,cin,cout,k", [(1, 5, 16, 16, 3, 64, 7), (2, 10, 12, 9, 1, 32, 7), (1, 3, 8, 8, 4, 128, 3)])
 def test_init_conv_weight_gradient_vs_torch(b, f, h, w, cin, cout, k):
     """init_conv (vdp.py:644) through InitConvFn: torch's forward, weight / bias gradient from vdmi_conv_wgrad_gather."""

@@ -178,6 +178,9 @@ _SIGNATURES = {
     "vdmi_rows_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int64]),
     "vdmi_rows_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 4 +
                         [C.c_int64, C.c_void_p, C.c_void_p]),
+    "vdmi_conv_wgrad_rows_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "vdmi_conv_wgrad_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 +
+                             [C.c_void_p, C.c_void_p]),
     "vdmi_conv_wgrad_gather_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "vdmi_conv_wgrad_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
     "vdmi_rmsnorm_silu_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64,

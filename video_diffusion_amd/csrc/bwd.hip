@@ -310,6 +310,126 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const RowsWgradArgs a) 
         part[((wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + (wave >> 1) * 32 + l31] = acc0[r] + acc1[r];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the (1,3,3) convolution straight from the channels-last rows (no transposed copies):
+//   dW[co][ci][ky][kx] = sum over frames and pixels p of dy[p][co] * x[p + (ky - 1, kx - 1)][ci]
+// The contraction runs over 16 consecutive pixels of an image row.  A workgroup stages a tile of TY image rows x XT
+// pixels of dy and the same tile of x with a one-pixel halo into LDS as the rows lie in memory (16-byte pieces), and
+// the waves read their fragments with the transposing LDS read, as wgrad_rows_kernel does: a tap is nothing but an
+// offset of (ky * (XT + 2) + kx) LDS rows on the x operand's address.  A wave walks down the TY rows of a 16-pixel
+// column and keeps the two upper rows of the 3 x 3 window in registers: three new x fragments and one dy fragment per
+// 16 pixels feed nine MFMAs.  Pixels outside the image are zeros in LDS.  Partial tiles in the format of
+// wgrad3x3_lds_kernel ([tap][64 co][64 ci] per workgroup), added by wgrad_reduce_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+struct Wgrad3RowsArgs {
+    const __bf16* x;
+    const __bf16* dy;
+    float* part;
+    int ldx, lddy, cin, cout, h, w, strips, ytiles;
+    long long units, per;        // units: (frame, strip, row tile) triples, row tile fastest; units per blockIdx.z
+};
+
+template <int XT, int TY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad3x3_rows_kernel(const Wgrad3RowsArgs a) {
+    constexpr int HX = XT + 2, XPX = HX * (TY + 2), DPX = XT * TY, P = RW_PITCH;
+    constexpr int XN = (XPX * 8 + 255) / 256, DN = DPX * 8 / 256;
+    static_assert(DPX * 8 % 256 == 0 && XT % 16 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xl = smem;                              // [(TY + 2) x (XT + 2) pixels][P]
+    char* dl = smem + XPX * P;                    // [TY x XT pixels][P]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+    const long long u_begin = (long long)blockIdx.z * a.per;
+    const long long u_end = u_begin + a.per < a.units ? u_begin + a.per : a.units;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // staging: piece tid + 256 k of a tile is (pixel (tid >> 3) + 32 k, channels 8 (tid & 7) ..)
+    const int ppx = tid >> 3, pc = tid & 7;
+    const bool a_ok = co0 + pc * 8 < a.cout, b_ok = ci0 + pc * 8 < a.cin;
+    bf16x8 xv[XN], dv[DN];
+    auto load = [&](long long u) {
+        const int yt = (int)(u % a.ytiles);
+        const long long t = u / a.ytiles;
+        const int strip = (int)(t % a.strips);
+        const long long frame = t / a.strips;
+        const int x0 = strip * XT, y0 = yt * TY;
+        const __bf16* xb = a.x + frame * a.h * a.w * a.ldx + ci0 + pc * 8;
+        const __bf16* db = a.dy + frame * a.h * a.w * a.lddy + co0 + pc * 8;
+#pragma unroll
+        for (int k = 0; k < XN; ++k) {
+            const int p = ppx + 32 * k, hy = p / HX, hx = p % HX;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool ok = b_ok && p < XPX && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+            xv[k] = ok ? *reinterpret_cast<const bf16x8*>(xb + ((long long)gy * a.w + gx) * a.ldx) : zero8;
+        }
+#pragma unroll
+        for (int k = 0; k < DN; ++k) {
+            const int p = ppx + 32 * k, ty = p / XT, tx = p % XT;
+            const int gy = y0 + ty, gx = x0 + tx;
+            const bool ok = a_ok && gy < a.h && gx < a.w;
+            dv[k] = ok ? *reinterpret_cast<const bf16x8*>(db + ((long long)gy * a.w + gx) * a.lddy) : zero8;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int k = 0; k < XN; ++k) {
+            const int p = ppx + 32 * k;
+            if (p < XPX) *reinterpret_cast<bf16x8*>(xl + p * P + pc * 16) = xv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < DN; ++k) *reinterpret_cast<bf16x8*>(dl + (ppx + 32 * k) * P + pc * 16) = dv[k];
+    };
+    // fragment addresses as in wgrad_rows_kernel: an LDS row is a pixel, 16 consecutive rows one contraction step
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int frag_row = 8 * (g >> 1) + q, frag_col = 16 * (g & 1) + 4 * pp;
+    const char* fa = dl + frag_row * P + (wm * 32 + frag_col) * 2;
+    const char* fb = xl + frag_row * P + (wn * 32 + frag_col) * 2;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (u_begin < u_end) {
+        load(u_begin);
+        for (long long u = u_begin; u < u_end; ++u) {
+            store();
+            __syncthreads();
+            if (u + 1 < u_end) load(u + 1);        // in flight during this tile's products
+#pragma unroll
+            for (int cx = 0; cx < XT / 16; ++cx) {
+                bf16x8 c[3][3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    c[0][kx] = lds_tr_fragment(fb + (0 * HX + cx * 16 + kx) * P);
+                    c[1][kx] = lds_tr_fragment(fb + (1 * HX + cx * 16 + kx) * P);
+                }
+#pragma unroll
+                for (int ty = 0; ty < TY; ++ty) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) c[2][kx] = lds_tr_fragment(fb + ((ty + 2) * HX + cx * 16 + kx) * P);
+                    const bf16x8 A = lds_tr_fragment(fa + (ty * XT + cx * 16) * P);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, c[ky][kx], acc[3 * ky + kx], 0, 0, 0);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) { c[0][kx] = c[1][kx]; c[1][kx] = c[2][kx]; }
+                }
+            }
+            __syncthreads();                       // the next tile overwrites both buffers
+        }
+    }
+    float* part = a.part + ((size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * (9 * 4096);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            part[(t * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + wn * 32 + l31] = acc[t][r];
+}
+
 // The same product with a 128 x 128 tile per workgroup (eight waves: 2 x 2 blocks of 64 x 64 output channels, times two
 // halves of a stage's 64 rows).  A 64 x 64 tile makes the launch read the rows of x once per 64 output channels and the
 // rows of dy once per 64 input channels through L2 - three to six times the operands' size on the layers of a training
@@ -1022,6 +1142,66 @@ extern "C" int vdmi_conv_wgrad(const void* xT, const void* dyT, float* dw, int c
     const long long elems = (long long)p.tx * p.ty * ntaps * 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, part, (int)p.gz, p.tx,
                        p.ty, ntaps, dw, cout, cin, cin_total, cin_off);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+namespace {
+struct Wgrad3RowsPlan { int tx, ty, strips, ytiles; bool narrow; long long units, per, gz; };
+int wgrad3_rows_plan(int cin, int cout, int nf, int h, int w, Wgrad3RowsPlan* p) {
+    if (cin <= 0 || cout <= 0 || cin % 8 || cout % 8 || nf <= 0 || h <= 0 || w <= 0) return VDMI_E_SHAPE;
+    if ((long long)nf * h * w > 0x7fffffffLL) return VDMI_E_SHAPE;
+    p->tx = (cout + 63) / 64;
+    p->ty = (cin + 63) / 64;
+    if (p->tx > 65535 || p->ty > 65535) return VDMI_E_SHAPE;
+    p->narrow = w <= 16;                                   // 16 x 8 pixel tiles instead of 32 x 4
+    const int xt = p->narrow ? 16 : 32, tyl = p->narrow ? 8 : 4;
+    p->strips = (w + xt - 1) / xt;
+    p->ytiles = (h + tyl - 1) / tyl;
+    p->units = (long long)nf * p->strips * p->ytiles;
+    // 62 KiB of LDS: two workgroups per CU, one round of 512 on the device; every workgroup writes a partial tile
+    long long split = 512 / ((long long)p->tx * p->ty);
+    if (split > p->units) split = p->units;
+    if (split < 1) split = 1;
+    p->per = (p->units + split - 1) / split;
+    p->gz = (p->units + p->per - 1) / p->per;
+    return p->gz > 65535 ? VDMI_E_SHAPE : VDMI_OK;
+}
+}   // namespace
+
+extern "C" size_t vdmi_conv_wgrad_rows_workspace_bytes(int cin, int cout, int nf, int h, int w) {
+    Wgrad3RowsPlan p;
+    if (wgrad3_rows_plan(cin, cout, nf, h, w, &p) != VDMI_OK) return 0;
+    return (size_t)p.gz * p.tx * p.ty * 9 * 4096 * sizeof(float);
+}
+
+extern "C" int vdmi_conv_wgrad_rows(const void* x, int ldx, const void* dy, int lddy, float* dw, int cin, int cout,
+                                    int cin_total, int cin_off, int nf, int h, int w, void* workspace, vdmi_stream stream) {
+    if (!x || !dy || !dw || !workspace) return VDMI_E_ARG;
+    if (cin_off < 0 || cin_off + cin > cin_total || ldx < cin || lddy < cout || ldx % 8 || lddy % 8) return VDMI_E_SHAPE;
+    Wgrad3RowsPlan p;
+    const int st = wgrad3_rows_plan(cin, cout, nf, h, w, &p);
+    if (st != VDMI_OK) return st;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return VDMI_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Wgrad3RowsArgs a;
+    a.x = static_cast<const __bf16*>(x);
+    a.dy = static_cast<const __bf16*>(dy);
+    a.part = static_cast<float*>(workspace);
+    a.ldx = ldx; a.lddy = lddy; a.cin = cin; a.cout = cout; a.h = h; a.w = w;
+    a.strips = p.strips; a.ytiles = p.ytiles; a.units = p.units; a.per = p.per;
+    const dim3 grid((unsigned)p.tx, (unsigned)p.ty, (unsigned)p.gz);
+    if (p.narrow) {
+        constexpr int lds = (18 * 10 + 128) * RW_PITCH;
+        hipLaunchKernelGGL((wgrad3x3_rows_kernel<16, 8>), grid, dim3(256), lds, s, a);
+    } else {
+        constexpr int lds = (34 * 6 + 128) * RW_PITCH;
+        hipLaunchKernelGGL((wgrad3x3_rows_kernel<32, 4>), grid, dim3(256), lds, s, a);
+    }
+    VDMI_LAUNCH_CHECK();
+    const long long elems = (long long)p.tx * p.ty * 9 * 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, a.part, (int)p.gz, p.tx,
+                       p.ty, 9, dw, cout, cin, cin_total, cin_off);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }

@@ -368,6 +368,26 @@ def conv_wgrad(x_t: torch.Tensor, dy_t: torch.Tensor, cin: int, cout: int, nf: i
     return dw
 
 
+# VDMI_WGRAD3_ROWS=0: the (1,3,3) weight gradient from transposed copies of its operands (A/B switch; the default
+# contracts over the pixels of the channels-last rows as they lie)
+_WGRAD3_ROWS = os.environ.get("VDMI_WGRAD3_ROWS", "1") != "0"
+
+
+def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, nf: int, h: int, w: int) -> torch.Tensor:
+    """float32 (cout, cin, 1, 3, 3) weight gradient of a (1,3,3) "same" convolution from its input rows x [nf*h*w][cin] and
+    output-gradient rows dy [nf*h*w][cout] (bf16, channels-last)."""
+    cin, cout = x.shape[1], dy.shape[1]
+    if not _WGRAD3_ROWS:
+        return conv_wgrad(rows_transposed(x, nf, h * w), rows_transposed(dy, nf, h * w), cin, cout, nf, h, w, 9)
+    assert x.shape[0] == dy.shape[0] == nf * h * w and x.is_contiguous() and dy.is_contiguous()
+    lib = _lib.lib()
+    dw = torch.empty(cout, cin, 1, 3, 3, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.vdmi_conv_wgrad_rows_workspace_bytes(cin, cout, nf, h, w), device=x.device, dtype=torch.uint8)
+    check(lib.vdmi_conv_wgrad_rows(x.data_ptr(), cin, dy.data_ptr(), cout, dw.data_ptr(), cin, cout, cin, 0, nf, h, w,
+                                   ws.data_ptr(), _stream()), "vdmi_conv_wgrad_rows")
+    return dw
+
+
 def rows_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     """float32 [cout][cin] weight gradient of a 1x1 convolution / Linear from its input rows x [rows][cin] and output-gradient
     rows dy [rows][cout] (bf16, channels-last) - no transposed copies."""
@@ -482,12 +502,11 @@ class ResnetBlockFn(torch.autograd.Function):
         dy2, dg2, db2, _, _ = rmsnorm_silu_bwd_rows(y2, do, g2v, None, None, b, f * hw)
         dw2 = None
         if need[6]:
-            dw2 = conv_wgrad(rows_transposed(h1, frames, hw), rows_transposed(dy2, frames, hw), cout, cout, frames, h, w, 9)
+            dw2 = conv3x3_wgrad(h1, dy2, frames, h, w)
         dh1 = conv_rows(dy2, param_pack(w2, True), None, frames, f, h, w)
         # block1
         dy1, dg1, db1, dscale, dshift = rmsnorm_silu_bwd_rows(y1, dh1, g1v, scale_c, shift_c, b, f * hw)
-        x_t = rows_transposed(xr, frames, hw) if need[3] else None
-        dw1 = conv_wgrad(x_t, rows_transposed(dy1, frames, hw), cin, cout, frames, h, w, 9) if need[3] else None
+        dw1 = conv3x3_wgrad(xr, dy1, frames, h, w) if need[3] else None
         # residual branch, then the input gradient: dgrad of conv1 + (res_conv's dgrad | the identity)
         if not ctx.with_res:
             dwres = dbres = dx_res = None

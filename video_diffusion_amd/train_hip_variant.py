@@ -23,8 +23,8 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .train_hip import (TemporalAttnFn, _act_dtype, _plain, _stream, attention_core_fits, colsum_rows, conv_rows, conv_wgrad,
-                        frame_conv_rows, frame_conv_wgrad, from_rows, param_pack, rows_transposed, rows_wgrad, to_rows, torch_ops)
+from .train_hip import (TemporalAttnFn, _act_dtype, _plain, _stream, attention_core_fits, colsum_rows, conv3x3_wgrad, conv_rows,
+                        frame_conv_rows, frame_conv_wgrad, from_rows, param_pack, rows_wgrad, to_rows, torch_ops)
 
 
 def _f(t):
@@ -117,7 +117,7 @@ class TemporalSpatialFn(torch.autograd.Function):
         dv, chan_s = groupnorm_bwd_rows(v, do, groups, gsv, besv, eps_s, b, 1, pg)
         dws = dbs = dgs = dbes = dscale = dshift = None
         if need[5]:
-            dws = conv_wgrad(rows_transposed(hmid, frames, hw), rows_transposed(dv, frames, hw), c, cout, frames, h, w, 9)
+            dws = conv3x3_wgrad(hmid, dv, frames, h, w)
         if need[6] or need[7] or need[8]:
             tot = chan_s.sum(0)
             dbes, dgs = tot[:, 0].contiguous(), tot[:, 1].contiguous()
