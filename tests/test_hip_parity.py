@@ -1084,17 +1084,22 @@ def test_errors_are_loud():
         m(torch.zeros(1, 3, 4, 8, 8), torch.zeros(1, dtype=torch.long))     # CPU tensors: no fallback
 
 
-@pytest.mark.parametrize("W,H,frames,c0,c1,n,ksplit", [
-    (8, 8, 10, 256, 0, 512, 1),        # four stacked frames per tile, last tile half empty
-    (8, 8, 8, 512, 0, 512, 3),         # contraction dealt to three workgroups per tile (unequal shares)
-    (8, 8, 12, 512, 512, 256, 4),      # two sources (skip concatenation)
-    (16, 16, 5, 128, 64, 256, 2),      # one frame per tile, two sources of different widths
-    (16, 32, 3, 64, 0, 128, 1),        # bands of a taller image: halo rows from the neighbouring band
-    (32, 32, 2, 128, 0, 128, 2),       # 8-row bands of a 32-pixel-wide image
-    (64, 64, 2, 128, 0, 256, 1),       # 4-row bands of a 64-pixel-wide image
-    (64, 12, 3, 64, 64, 128, 2),       # the same, three bands per frame, two sources
+@pytest.mark.parametrize("W,H,frames,c0,c1,n,ksplit,ld_res", [
+    (8, 8, 10, 256, 0, 512, 1, 0),        # four stacked frames per tile, last tile half empty
+    (8, 8, 8, 512, 0, 512, 3, 0),         # contraction dealt to three workgroups per tile (unequal shares)
+    (8, 8, 12, 512, 512, 256, 4, 0),      # two sources (skip concatenation)
+    (16, 16, 5, 128, 64, 256, 2, 0),      # one frame per tile, two sources of different widths
+    (16, 32, 3, 64, 0, 128, 1, 0),        # bands of a taller image: halo rows from the neighbouring band
+    (32, 32, 2, 128, 0, 128, 2, 0),       # 8-row bands of a 32-pixel-wide image
+    (64, 64, 2, 128, 0, 256, 1, 0),       # 4-row bands of a 64-pixel-wide image
+    (64, 12, 3, 64, 64, 128, 2, 0),       # the same, three bands per frame, two sources
+    # + identity residual rows (the training step's input gradient of a block's first convolution); ld_res: their pitch
+    (8, 8, 10, 256, 0, 512, 1, 512),
+    (16, 16, 5, 256, 0, 128, 1, 136),
+    (32, 32, 2, 128, 0, 256, 1, 256),
+    (64, 12, 3, 256, 0, 128, 1, 128),
 ])
-def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, ksplit):
+def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, ksplit, ld_res):
     """The streaming (1,3,3) convolution of the wide layers (Block.proj, reference vdp.py:412-420) against the general
     tap-GEMM on the same arguments and against torch's conv2d on the bf16-rounded operands.  Both kernels add the same
     bf16 products in fp32 in the same order; they differ in when the bias joins the sum, so single roundings may flip."""
@@ -1109,6 +1114,7 @@ def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, kspli
     x0 = inp(f"dconv.x0.{W}.{c0}", (frames * H * W, c0)).to(ACT).to(dev())
     x1 = inp(f"dconv.x1.{W}.{c1}", (frames * H * W, c1)).to(ACT).to(dev()) if c1 else None
     rows = frames * H * W
+    res = inp(f"dconv.res.{W}.{n}", (rows, ld_res)).to(ACT).to(dev()) if ld_res else None
 
     def run(enable):
         out = torch.full((ksplit * rows, n), float("nan"), device=dev(), dtype=ACT)
@@ -1122,6 +1128,8 @@ def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, kspli
         a.tile_bn = 64
         if ksplit > 1:
             a.k_split, a.out_split_stride = ksplit, rows * n
+        if res is not None:
+            a.has_res, a.res_identity, a.ld_res = 2, res.data_ptr(), ld_res
         lib.vdmi_dconv_enable(1 if enable else 0)
         try:
             assert lib.vdmi_dconv_covers(C.byref(a)) == (1 if enable else 0)
@@ -1137,6 +1145,8 @@ def test_streaming_conv_matches_tapgemm_and_torch(W, H, frames, c0, c1, n, kspli
     xi = x.reshape(frames, H, W, cin).permute(0, 3, 1, 2)
     ref = torch.nn.functional.conv2d(xi, bf16_round(wt).reshape(n, cin, 3, 3), bias.cpu(), padding=1)
     ref = ref.permute(0, 2, 3, 1).reshape(rows, n)
+    if res is not None:
+        ref = ref + res.float().cpu()[:, :n]
     assert rel_err(y_new, ref) < 4e-3 * max(1, ksplit) ** 0.5        # one bf16 rounding per partial sum
     assert rel_err(y_new, y_old) < 2e-3
     assert (y_new != y_old).float().mean() < 0.05

@@ -84,9 +84,10 @@ __device__ __forceinline__ void wait_vm() {
 // 2 wk + 1 of every (chunk, tap) step over all 64 channels (the same 64 x 64 block per wave, 8 MFMAs per wave and step),
 // weight tiles are 8 KiB, and the two partial blocks of a pixel group are added through LDS before the epilogue, which
 // each wave then runs for 32 of the 64 pixels with all of their channels in its own registers.  NORM only.
-template <int W, int R, bool NORM, bool N64 = false>
+template <int W, int R, bool NORM, bool N64 = false, bool PRES = false>
 __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
     static_assert(!N64 || NORM, "the 64-channel form exists with the normalisation epilogue only");
+    static_assert(!PRES || !NORM, "PRES: the plain epilogue + an identity residual (the normalising one takes a.res as it is)");
     constexpr int NF = 256 / (R * W), PW = W + 2, PR = R + 2, NPP = NF * PR * PW;
     constexpr int NPIECE = (NPP + 7) / 8, PBUF = NPIECE * 1024, NU = (NPIECE + 7) / 8;
     constexpr int S = (W == 8) ? 4 : 0;
@@ -463,6 +464,19 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
                         acc[i][j][4 * rg + e] = silu_f(fmaf(acc[i][j][4 * rg + e] * rinv[j], gv[e], sv[e]));
             }
     }
+    if constexpr (PRES) {
+        // identity residual of the plain epilogue (the input gradient of a block's first convolution + the gradient of
+        // its residual branch): through the wave's own staging rows, as above; a wave reads only what it wrote
+        if (a.res) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = k * 8 + srow0;
+                bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (row0 + row < a.rows) rv = *reinterpret_cast<const bf16x8*>(a.res + (row0 + row) * a.ld_res + n0 + schunk * 8);
+                *reinterpret_cast<bf16x8*>(stg + row * SROW + schunk * 8) = rv;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -473,7 +487,7 @@ __global__ __launch_bounds__(512) void dconv_kernel(const DcArgs a) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e];
-                if constexpr (NORM) {
+                if constexpr (NORM || PRES) {
                     if (a.res) {
                         const bf16x4 rv = *reinterpret_cast<const bf16x4*>(sp);
 #pragma unroll
@@ -528,8 +542,11 @@ bool dc_covers(const vdmi_tapgemm_args& A) {
         if (A.has_res == 2 && (!A.res_identity || A.ld_res % 8 || !aligned16(A.res_identity))) return false;
         if (A.gain_bstride % 4 || A.shift_bstride % 4 || !aligned16(A.gain) || (A.shift && !aligned16(A.shift))) return false;
         if (A.n == 64 && A.main.in_w != 32 && A.main.in_w != 64 && !g_dc_norm_all) return false;
-    } else if (A.epilogue != VDMI_EPI_PLAIN || A.act || A.has_res || A.n % 128 || A.tile_bn != 64) {
-        return false;
+    } else {
+        if (A.epilogue != VDMI_EPI_PLAIN || A.act || A.has_res == 1 || A.n % 128 || A.tile_bn != 64) return false;
+        // plain + identity residual: one share only (the residual is added where the sum is complete)
+        if (A.has_res == 2 && (A.k_split > 1 || !A.res_identity || A.ld_res % 8 || A.ld_res < A.n || !aligned16(A.res_identity)))
+            return false;
     }
     if (m.ntaps != 9 || m.stride != 1 || m.c0 <= 0 || m.c0 % 64 || m.c1 % 64) return false;
     for (int t = 0; t < 9; ++t)
@@ -598,7 +615,7 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     k.shift = A.shift;
     k.gain_bs = A.gain_bstride;
     k.shift_bs = A.shift_bstride;
-    k.res = (norm && A.has_res == 2) ? static_cast<const __bf16*>(A.res_identity) : nullptr;
+    k.res = A.has_res == 2 ? static_cast<const __bf16*>(A.res_identity) : nullptr;
     k.ld_res = A.ld_res;
     k.fpb = A.frames_per_batch > 0 ? A.frames_per_batch : 1;
     k.norm_scale = A.norm_scale;
@@ -609,7 +626,7 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     const long long nwg = (long long)k.npx * k.nnt * k.ksplit;
     if (nwg > 0x7fffffffLL) return VDMI_E_SHAPE;
 
-    static std::atomic<uint64_t> attr_mask[12];
+    static std::atomic<uint64_t> attr_mask[16];
     const int PW = W + 2, PR = R + 2, NF = 256 / (R * W);
     const int npiece = (NF * PR * PW + 7) / 8;
     const size_t lds = (size_t)2 * npiece * 1024 + 3 * (n64 ? 8192 : 16384);
@@ -627,6 +644,16 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
         if (vdmi_set_max_lds(reinterpret_cast<const void*>(fn), attr_mask[IDX_], 160 * 1024)) return VDMI_E_LAUNCH; \
         hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(512), need, stream, k);                                   \
     }
+#define VDMI_DC_CASE_RES(W_, R_, IDX_)                                                                             \
+    {                                                                                                              \
+        auto fn = dconv_kernel<W_, R_, false, false, true>;                                                        \
+        if (vdmi_set_max_lds(reinterpret_cast<const void*>(fn), attr_mask[IDX_], 160 * 1024)) return VDMI_E_LAUNCH; \
+        hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(512), need, stream, k);                                   \
+    }
+    if (!norm && k.res) {
+        if (W == 8) VDMI_DC_CASE_RES(8, 8, 12) else if (W == 16) VDMI_DC_CASE_RES(16, 16, 13)
+        else if (W == 32) VDMI_DC_CASE_RES(32, 8, 14) else VDMI_DC_CASE_RES(64, 4, 15)
+    } else
     if (n64) {
         if (W == 8) VDMI_DC_CASE64(8, 8, 8) else if (W == 16) VDMI_DC_CASE64(16, 16, 9)
         else if (W == 32) VDMI_DC_CASE64(32, 8, 10) else VDMI_DC_CASE64(64, 4, 11)
@@ -637,6 +664,7 @@ int vdmi_dconv_try(const vdmi_tapgemm_args& A, hipStream_t stream) {
     else { if (norm) VDMI_DC_CASE(64, 4, true, 6) else VDMI_DC_CASE(64, 4, false, 7) }
 #undef VDMI_DC_CASE
 #undef VDMI_DC_CASE64
+#undef VDMI_DC_CASE_RES
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }
