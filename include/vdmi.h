@@ -554,6 +554,11 @@ int vdmi_rmsnorm_silu_bwd_ws(const void* y, int ldy, const void* dh, int ldh, vo
 
 /* out[ch] += sum over rows of x[row][ch]  (bias gradient of res_conv, vdp.py:439); x bf16 [rows][ld], c <= 2048. */
 int vdmi_colsum(const void* x, int ld, int64_t rows, int c, float* out, vdmi_stream stream);
+/* out[ch] = the same sum, WRITTEN, without float atomics: per-workgroup partial sums in `workspace`
+ * (vdmi_colsum_workspace_bytes() bytes, 16-byte aligned) added in a fixed order by a second launch - the same bits on
+ * every run. */
+size_t vdmi_colsum_workspace_bytes(int64_t rows, int c);   /* HOST */
+int vdmi_colsum_ws(const void* x, int ld, int64_t rows, int c, float* out, void* workspace, vdmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training kernels of the temporal attention layer, Residual(PreNorm(EinopsToAndFrom('b c f h w', 'b (h w) f c',

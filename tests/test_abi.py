@@ -222,6 +222,11 @@ def test_backward_entry_points_reject_bad_arguments():
                                         16, None) == E_SHAPE
     assert lib.vdmi_colsum(None, 64, 10, 64, None, None) == E_ARG
     assert lib.vdmi_colsum(16, 64, 10, 4096, 16, None) == E_SHAPE
+    assert lib.vdmi_colsum_workspace_bytes(5000, 64) == ((5000 + 511) // 512) * 64 * 4
+    assert lib.vdmi_colsum_workspace_bytes(10, 4096) == 0
+    assert lib.vdmi_colsum_ws(16, 64, 10, 64, 16, None, None) == E_ARG
+    assert lib.vdmi_colsum_ws(16, 64, 10, 64, 16, 8, None) == E_ALIGN
+    assert lib.vdmi_colsum_ws(16, 64, 10, 4096, 16, 16, None) == E_SHAPE
 
 
 def test_attention_training_entry_points_reject_bad_arguments():

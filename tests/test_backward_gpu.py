@@ -182,12 +182,17 @@ def test_rmsnorm_silu_bwd_vs_torch(c, batch, rpb, with_ss, form, monkeypatch):
         assert record(tag + ".dshift", rel_err(dshift.cpu(), hr.grad.cpu()), 2e-3) < 2e-3
 
 
-def test_colsum():
+@pytest.mark.parametrize("form", ["fixed_order", "atomic"])
+def test_colsum(form, monkeypatch):
     from video_diffusion_amd import train_hip as T
+    monkeypatch.setattr(T, "_NORM_BWD_FIXED_ORDER", form == "fixed_order")
     g = torch.Generator().manual_seed(5)
-    for rows, c in [(5000, 64), (333, 1024), (70, 8)]:
+    for rows, c in [(5000, 64), (333, 1024), (70, 8), (262144, 128), (1000, 72), (3, 2048)]:
         x = _bf(torch.randn(rows, c, generator=g)).to(DEV)
-        assert rel_err(T.colsum_rows(x).cpu(), x.double().sum(0).cpu()) < 1e-4
+        out = T.colsum_rows(x)
+        assert rel_err(out.cpu(), x.double().sum(0).cpu()) < 1e-4
+        if form == "fixed_order":
+            assert torch.equal(out, T.colsum_rows(x))
 
 
 def _rand_block(cin, cout, temb_dim, seed):

@@ -191,6 +191,8 @@ _SIGNATURES = {
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float] +
                                  [C.c_void_p] * 6),
     "vdmi_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "vdmi_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "vdmi_colsum_ws": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdmi_layernorm_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "vdmi_layernorm_rows_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "vdmi_tattn_core_fits": (C.c_int, [C.c_int] * 4),

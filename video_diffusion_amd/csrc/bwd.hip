@@ -921,8 +921,10 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_bwd_kernel(const NormBwdArgs
 }
 
 // out[c] += sum over rows of x[row][c]   (bias gradient of a convolution whose output gradient is x)
+// part: per-workgroup sums [chunk][c] for colsum_reduce_kernel (then out is not touched), or null
 __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ x, int ld, long long rows, int c,
-                                                     long long rows_per_chunk, float* __restrict__ out) {
+                                                     long long rows_per_chunk, float* __restrict__ out,
+                                                     float* __restrict__ part) {
     __shared__ float colred[2048];
     const int tid = threadIdx.x, LP = c / 8, R = 256 / LP, piece = tid % LP, rslot = tid / LP;
     for (int i = tid; i < c; i += 256) colred[i] = 0.f;
@@ -936,11 +938,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
             for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
         }
     __syncthreads();
+    if (part) {
+        // no atomics: the row slots' sums side by side in LDS ([slot][c], at most 2048 floats), added in slot order
+        if (rslot < R)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) colred[rslot * c + piece * 8 + e] = s[e];
+        __syncthreads();
+        for (int i = tid; i < c; i += 256) {
+            float sum = 0.f;
+            for (int rs = 0; rs < R; ++rs) sum += colred[rs * c + i];
+            part[(size_t)blockIdx.x * c + i] = sum;
+        }
+        return;
+    }
     if (rslot < R)
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(&colred[piece * 8 + e], s[e]);
     __syncthreads();
     for (int i = tid; i < c; i += 256) unsafeAtomicAdd(out + i, colred[i]);
+}
+
+// out[i] = sum over chunks of part[chunk][i], in a fixed order: 32 channels x 32 interleaved chains per workgroup
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ part, int chunks, int c,
+                                                             float* __restrict__ out) {
+    __shared__ float red[32][33];
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31), chain = threadIdx.x >> 5;
+    float s = 0.f;
+    if (i < c) {
+#pragma unroll 8
+        for (int k = chain; k < chunks; k += 32) s += part[(size_t)k * c + i];
+    }
+    red[chain][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (chain == 0 && i < c) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
+        out[i] = t;
+    }
 }
 
 // dgamma[i], dbias[i] = sum over samples and chunks, dscale[b][i], dshift[b][i] = sum over chunks of the per-workgroup
@@ -1371,7 +1406,7 @@ extern "C" int vdmi_rmsnorm_silu_bwd_ws(const void* y, int ldy, const void* dh, 
                                  dgamma, dbias, dscale, dshift, workspace, stream);
 }
 
-extern "C" int vdmi_colsum(const void* x, int ld, int64_t rows, int c, float* out, vdmi_stream stream) {
+static int colsum_impl(const void* x, int ld, int64_t rows, int c, float* out, void* workspace, vdmi_stream stream) {
     if (!x || !out) return VDMI_E_ARG;
     if (rows <= 0 || c < 8 || c > 2048 || c % 8 || ld % 8 || ld < c) return VDMI_E_SHAPE;
     if (!aligned16(x)) return VDMI_E_ALIGN;
@@ -1380,8 +1415,30 @@ extern "C" int vdmi_colsum(const void* x, int ld, int64_t rows, int c, float* ou
     const long long per = (long long)R * 16;
     const long long chunks = (rows + per - 1) / per;
     if (chunks > 0x7fffffffLL) return VDMI_E_SHAPE;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const __bf16*>(x), ld, (long long)rows, c, per, out);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)chunks), dim3(256), 0, st, static_cast<const __bf16*>(x), ld,
+                       (long long)rows, c, per, out, static_cast<float*>(workspace));
     VDMI_LAUNCH_CHECK();
+    if (workspace) {
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((c + 31) / 32)), dim3(1024), 0, st,
+                           static_cast<const float*>(workspace), (int)chunks, c, out);
+        VDMI_LAUNCH_CHECK();
+    }
     return VDMI_OK;
+}
+
+extern "C" int vdmi_colsum(const void* x, int ld, int64_t rows, int c, float* out, vdmi_stream stream) {
+    return colsum_impl(x, ld, rows, c, out, nullptr, stream);
+}
+
+extern "C" size_t vdmi_colsum_workspace_bytes(int64_t rows, int c) {
+    if (rows <= 0 || c < 8 || c > 2048 || c % 8) return 0;
+    const long long per = (long long)(256 / (c / 8)) * 16;
+    return (size_t)((rows + per - 1) / per) * c * sizeof(float);
+}
+
+extern "C" int vdmi_colsum_ws(const void* x, int ld, int64_t rows, int c, float* out, void* workspace, vdmi_stream stream) {
+    if (!workspace) return VDMI_E_ARG;
+    if (!aligned16(workspace)) return VDMI_E_ALIGN;
+    return colsum_impl(x, ld, rows, c, out, workspace, stream);
 }

@@ -445,8 +445,16 @@ def rmsnorm_silu_bwd_rows(y, dh, gamma, scale, shift, batch, rows_per_batch, wan
 
 
 def colsum_rows(x: torch.Tensor) -> torch.Tensor:
-    out = torch.zeros(x.shape[1], device=x.device, dtype=torch.float32)
-    check(_lib.lib().vdmi_colsum(x.data_ptr(), x.shape[1], x.shape[0], x.shape[1], out.data_ptr(), _stream()), "vdmi_colsum")
+    """float32 [c] column sums of bf16 rows (a bias gradient); fixed-order partial sums unless VDMI_NORM_BWD_ATOMIC=1."""
+    lib = _lib.lib()
+    rows, c = x.shape
+    if _NORM_BWD_FIXED_ORDER:
+        out = torch.empty(c, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.vdmi_colsum_workspace_bytes(rows, c), device=x.device, dtype=torch.uint8)
+        check(lib.vdmi_colsum_ws(x.data_ptr(), c, rows, c, out.data_ptr(), ws.data_ptr(), _stream()), "vdmi_colsum_ws")
+        return out
+    out = torch.zeros(c, device=x.device, dtype=torch.float32)
+    check(lib.vdmi_colsum(x.data_ptr(), c, rows, c, out.data_ptr(), _stream()), "vdmi_colsum")
     return out
 
 
