@@ -399,3 +399,28 @@ def test_trainer_hip_backend_with_gradient_accumulation_keeps_weight_sets_fresh(
     assert len(ref) == len(hip) == 3
     for i, (a, b) in enumerate(zip(hip, ref)):
         assert record(f"trainer_hip_accum2.loss_step{i}", abs(a - b) / abs(b), 3e-2) < 3e-2
+
+
+def test_time_tables_equal_the_blocks_own_time_mlps():
+    """train_hip.time_tables: the ResnetBlocks' time MLPs (vdp.py:432-436, 445-447) as one Linear over the concatenated
+    weights give every block the values and the parameter / embedding gradients of its own MLP (CPU: plain torch ops)."""
+    import torch.nn.functional as F
+    from video_diffusion_amd import Unet3D, train_hip
+    torch.manual_seed(0)
+    unet = Unet3D(dim=32, dim_mults=(1, 2), channels=1)
+    blocks = [m for m in unet.modules() if getattr(m, "mlp", None) is not None and hasattr(m, "block1")]
+    temb = torch.randn(3, blocks[0].mlp[1].in_features, requires_grad=True)
+    tables = train_hip.time_tables(unet, temb).tables
+    assert tables is not None and len(tables) == len(blocks) >= 8
+    own = [m.mlp[1](F.silu(temb)) for m in blocks]
+    for m, e in zip(blocks, own):
+        assert torch.allclose(tables[id(m)], e, atol=1e-6)
+    weights = [m.mlp[1].weight for m in blocks] + [m.mlp[1].bias for m in blocks] + [temb]
+    probe = [torch.randn_like(e) for e in own]
+    g_tab = torch.autograd.grad(sum((tables[id(m)] * p).sum() for m, p in zip(blocks, probe)), weights)
+    g_own = torch.autograd.grad(sum((e * p).sum() for e, p in zip(own, probe)), weights)
+    for a, b in zip(g_tab, g_own):
+        assert torch.allclose(a, b, atol=1e-5)
+    # a model without time-conditioned blocks, or a foreign embedding width: no tables, the blocks run their own MLPs
+    assert train_hip.time_tables(unet, torch.randn(3, 7)).tables is None
+    assert train_hip.time_tables(unet, None).tables is None

@@ -299,6 +299,14 @@ def _unet_forward(unet, x, time, cond, null_cond_prob, frame_cond_features, null
         if null_frame_cond_prob > 0:
             ctx = ctx * (1 - _mask((batch,), null_frame_cond_prob, device)[:, None, None].float())
 
+    if _HIP_RESNET and x.is_cuda:
+        from .train_hip import time_tables      # the blocks' time MLPs as one Linear
+        with time_tables(unet, t):
+            return _unet_body(unet, x, r, t, ctx, bias, focus)
+    return _unet_body(unet, x, r, t, ctx, bias, focus)
+
+
+def _unet_body(unet, x, r, t, ctx, bias, focus):
     skips = []
     for i, (b1, b2, sattn, tattn, down) in enumerate(unet.downs):
         x = _resnet(b2, _resnet(b1, x, t), t)

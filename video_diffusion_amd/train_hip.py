@@ -662,12 +662,52 @@ class TemporalConvResFn(torch.autograd.Function):
         return dh, dx, dwt, dbt, dwres, dbres
 
 
+# VDMI_TIME_TABLES=0: every ResnetBlock runs its own time MLP (A/B switch)
+_TIME_TABLES_ON = os.environ.get("VDMI_TIME_TABLES", "1") != "0"
+_TIME_TABLES = None     # {id(ResnetBlock): its [B][2 Cout] slice} for the forward in progress, or None
+
+
+class time_tables:
+    """`with time_tables(unet, temb):` - the time MLPs of all ResnetBlocks of `unet` (ResnetBlock.mlp = SiLU + Linear,
+    vdp.py:432-436, 445-447) as ONE Linear over the concatenated weights; resnet_block() then takes its block's slice.
+    The blocks' small matmuls, their SiLUs and, in the backward, the per-block products and the additions into the
+    embedding's gradient (~9 launches per block) become a handful of launches for the model; under autocast the
+    weights are narrowed once.  Same function of the same parameters: autograd splits the gradient back."""
+
+    def __init__(self, unet, temb):
+        self.tables = None
+        if not _TIME_TABLES_ON or temb is None:
+            return
+        blocks = [m for m in unet.modules() if getattr(m, "mlp", None) is not None and hasattr(m, "block1")
+                  and isinstance(m.mlp, torch.nn.Sequential) and isinstance(m.mlp[1], torch.nn.Linear)
+                  and m.mlp[1].in_features == temb.shape[1]]
+        if len(blocks) < 2:
+            return
+        w = torch.cat([m.mlp[1].weight for m in blocks], dim=0)
+        b = torch.cat([m.mlp[1].bias for m in blocks], dim=0)
+        e = F.linear(F.silu(temb), w, b)
+        parts = e.split([m.mlp[1].out_features for m in blocks], dim=1)
+        self.tables = {id(m): p for m, p in zip(blocks, parts)}
+
+    def __enter__(self):
+        global _TIME_TABLES
+        self.prev, _TIME_TABLES = _TIME_TABLES, self.tables
+        return self
+
+    def __exit__(self, *exc):
+        global _TIME_TABLES
+        _TIME_TABLES = self.prev
+        return False
+
+
 def resnet_block(rb, x: torch.Tensor, temb) -> torch.Tensor:
     """autograd.py's `_resnet` on the HIP kernels.  The variant's block (version1diffusion.py:308, 320-323: a (3,1,1)
     convolution over frames between block2 and the residual) runs its two Blocks here and the rest as torch ops."""
     scale = shift = None
     if rb.mlp is not None:
-        e = rb.mlp[1](F.silu(temb))
+        e = _TIME_TABLES.get(id(rb)) if _TIME_TABLES is not None else None
+        if e is None:
+            e = rb.mlp[1](F.silu(temb))
         scale, shift = e.chunk(2, dim=1)
     rc = rb.res_conv
     wres, bres = (rc.weight, rc.bias) if isinstance(rc, torch.nn.Conv3d) else (None, None)
