@@ -523,6 +523,18 @@ size_t vdmi_conv_wgrad_rows_workspace_bytes(int cin, int cout, int nf, int h, in
 int vdmi_conv_wgrad_rows(const void* x, int ldx, const void* dy, int lddy, float* dw, int cin, int cout, int cin_total,
                          int cin_off, int nf, int h, int w, void* workspace, vdmi_stream stream);
 
+/* Weight gradient of the (1,4,4) / stride 2 / pad 1 convolution between a big image (h x w, even) and a small one
+ * (h/2 x w/2), straight from the channels-last rows:
+ *   dw[cs][cb][ky][kx] = sum over frames and small pixels q of small[q][cs] * big[2 q + (ky - 1, kx - 1)][cb]
+ * big [nf*h*w][ldb] (cb channels), small [nf*(h/2)*(w/2)][lds] (cs channels), both bf16; dw float [cs][cb][4][4],
+ * written.  Downsample (vdp.py:377-378): big = its input rows, small = its output gradient, dw = the weight gradient
+ * (cout, cin, 1, 4, 4); Upsample's ConvTranspose3d (vdp.py:374-375): big = its output gradient, small = its input rows,
+ * dw = the weight gradient (cin, cout, 1, 4, 4).  cb, cs, ldb, lds multiples of 8.
+ * workspace: vdmi_strided_wgrad_rows_workspace_bytes() bytes (0: shape not taken). */
+size_t vdmi_strided_wgrad_rows_workspace_bytes(int cb, int cs, int nf, int h, int w);   /* HOST */
+int vdmi_strided_wgrad_rows(const void* big, int ldb, const void* small, int lds, float* dw, int cb, int cs, int nf, int h,
+                            int w, void* workspace, vdmi_stream stream);
+
 /* The same gradient for a (1,kh,kw) "same" convolution with few input channels (Unet3D.init_conv, vdp.py:644: 3 -> dim,
  * 7 x 7): a column of the contraction is a (ci, ky, kx) triple, so no lane idles on padding channels.  kh, kw odd;
  * dw float [cout][cin][kh][kw], written (not accumulated); workspace: vdmi_conv_wgrad_gather_workspace_bytes() bytes. */

@@ -203,6 +203,11 @@ def test_backward_entry_points_reject_bad_arguments():
     assert lib.vdmi_conv_wgrad_rows(16, 64, 16, 64, 16, 64, 64, 64, 8, 2, 8, 8, 16, None) == E_SHAPE   # window past cin_total
     assert lib.vdmi_conv_wgrad_rows(16, 32, 16, 64, 16, 64, 64, 64, 0, 2, 8, 8, 16, None) == E_SHAPE   # row pitch below cin
     assert lib.vdmi_conv_wgrad_rows(16, 64, 16, 64, 16, 64, 64, 64, 0, 2, 8, 8, 8, None) == E_ALIGN
+    assert lib.vdmi_strided_wgrad_rows_workspace_bytes(128, 128, 16, 128, 128) == 64 * 2 * 4 * 16 * 2048 * 4
+    assert lib.vdmi_strided_wgrad_rows_workspace_bytes(128, 128, 16, 127, 128) == 0                   # odd image
+    assert lib.vdmi_strided_wgrad_rows(None, 64, 16, 64, 16, 64, 64, 2, 8, 8, 16, None) == E_ARG
+    assert lib.vdmi_strided_wgrad_rows(16, 32, 16, 64, 16, 64, 64, 2, 8, 8, 16, None) == E_SHAPE      # row pitch below cb
+    assert lib.vdmi_strided_wgrad_rows(16, 64, 16, 64, 16, 64, 64, 2, 8, 8, 8, None) == E_ALIGN
     assert lib.vdmi_rmsnorm_silu_bwd(None, 64, 16, 64, 16, 64, 1, 10, 64, None, None, None, 0, 8.0, None, None, None,
                                      None, None) == E_ARG
     assert lib.vdmi_rmsnorm_silu_bwd(16, 96, 16, 96, 16, 96, 1, 10, 96, 16, None, None, 0, 9.8, 16, None, None, None,

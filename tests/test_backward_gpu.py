@@ -101,6 +101,29 @@ def test_conv_wgrad_rows_vs_torch(nf, h, w, cin, cout):
     assert rel_err(dw.cpu(), old.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("nf,h,w,cb,cs", [(3, 16, 16, 64, 64), (2, 32, 32, 128, 64), (5, 8, 12, 72, 40), (1, 2, 2, 8, 8),
+                                          (2, 64, 64, 64, 128), (16, 26, 38, 32, 96), (3, 128, 128, 64, 64)])
+def test_strided_wgrad_rows_vs_torch(nf, h, w, cb, cs, monkeypatch):
+    """vdmi_strided_wgrad_rows (weight gradient of Downsample's (1,4,4) / stride 2 / pad 1 convolution, vdp.py:377-378, from
+    the rows as they lie): against torch's conv2d weight gradient and against the four-one-tap form; ragged tiles (heights
+    that are no multiple of 6 small rows, widths no multiple of 16 small pixels, channel counts off the tile sizes)."""
+    from video_diffusion_amd import train_hip as T
+    g = torch.Generator().manual_seed(11)
+    big = _bf(torch.randn(nf * h * w, cb, generator=g)).to(DEV)
+    small = _bf(torch.randn(nf * (h // 2) * (w // 2), cs, generator=g)).to(DEV)
+    assert T._STRIDED_WGRAD_ROWS
+    dw = T.strided_wgrad(big, small, nf, h, w)
+    xi = big.float().view(nf, h, w, cb).permute(0, 3, 1, 2)
+    gi = small.float().view(nf, h // 2, w // 2, cs).permute(0, 3, 1, 2)
+    wt = torch.zeros(cs, cb, 4, 4, device=DEV, requires_grad=True)
+    F.conv2d(xi.double(), wt.double(), stride=2, padding=1).backward(gi.double())
+    err = record(f"strided_wgrad.nf{nf}.{h}x{w}.{cb}to{cs}", rel_err(dw.view(cs, cb, 4, 4).cpu(), wt.grad.cpu()), 1e-3)
+    assert err < 1e-3
+    assert torch.equal(dw, T.strided_wgrad(big, small, nf, h, w))
+    monkeypatch.setattr(T, "_STRIDED_WGRAD_ROWS", False)
+    assert rel_err(dw.cpu(), T.strided_wgrad(big, small, nf, h, w).cpu()) < 1e-4
+
+
 @pytest.mark.parametrize("b,f,h,w,cin,cout,k", [(1, 5, 16, 16, 3, 64, 7), (2, 10, 12, 9, 1, 32, 7), (1, 3, 8, 8, 4, 128, 3)])
 def test_init_conv_weight_gradient_vs_torch(b, f, h, w, cin, cout, k):
     """init_conv (vdp.py:644) through InitConvFn: torch's forward, weight / bias gradient from vdmi_conv_wgrad_gather."""

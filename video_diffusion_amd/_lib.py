@@ -181,6 +181,9 @@ _SIGNATURES = {
     "vdmi_conv_wgrad_rows_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "vdmi_conv_wgrad_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 +
                              [C.c_void_p, C.c_void_p]),
+    "vdmi_strided_wgrad_rows_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "vdmi_strided_wgrad_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 +
+                                [C.c_void_p, C.c_void_p]),
     "vdmi_conv_wgrad_gather_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "vdmi_conv_wgrad_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
     "vdmi_rmsnorm_silu_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64,

@@ -430,6 +430,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             part[(t * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + wn * 32 + l31] = acc[t][r];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the (1,4,4) / stride 2 / pad 1 convolution (Downsample, vdp.py:377-378; with the roles of input and
+// output gradient swapped, of the transposed convolution of Upsample, vdp.py:374-375) straight from the channels-last rows:
+//   dW[cs][cb][ky][kx] = sum over frames and small-image pixels q of small[q][cs] * big[2 q + (ky - 1, kx - 1)][cb]
+// Same scheme as wgrad3x3_rows_kernel: the contraction runs over 16 consecutive pixels of a small-image row, the operands
+// are staged as the rows lie and read with the transposing LDS read; the big image's fragment takes every second LDS row
+// (a lane's address is free), a tap is an offset of ky * (2 XT + 2) + kx rows.  Sixteen taps x a 32 x 32 block would be
+// 256 accumulators, so the workgroup's tile is 64 (cs) x 32 (cb) and its waves are (cs half) x (ky parity): a wave keeps
+// the taps ky in {kyp, kyp + 2}, kx in 0..3 (128 accumulators) and, walking down the rows of a 16-pixel column, the
+// fragments of tap row kyp + 2 become those of tap row kyp one step later: four new big fragments and one small
+// fragment per eight MFMAs.  The big tile's rows are 96 bytes apart (64 bytes of channels + 32): rows two apart then
+// fall 48 banks apart and a half-wave's four rows x 64 bytes cover all 64 banks once.
+// Partial tiles [16 taps][64 cs][32 cb] per workgroup, added in a fixed order by wgrad4_reduce_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int W4_XT = 16, W4_TY = 6, W4_PB = 96;
+constexpr int W4_HXB = 2 * W4_XT + 2, W4_BPX = W4_HXB * (2 * W4_TY + 2), W4_SPX = W4_XT * W4_TY;
+constexpr int W4_LDS = W4_BPX * W4_PB + W4_SPX * RW_PITCH;
+
+struct Wgrad4Args {
+    const __bf16* big;
+    const __bf16* small;
+    float* part;
+    int ldb, lds, cb, cs, h, w, strips, ytiles;      // h x w: the big image
+    long long units, per;                            // units: (frame, strip, row tile) triples, row tile fastest
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad4x4s2_rows_kernel(const Wgrad4Args a) {
+    constexpr int XT = W4_XT, TY = W4_TY, HXB = W4_HXB, BPX = W4_BPX, SPX = W4_SPX, PB = W4_PB, PS = RW_PITCH;
+    constexpr int BN = (BPX * 4 + 255) / 256, SN = SPX * 8 / 256;
+    static_assert(SPX * 8 % 256 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* bl = smem;                              // [(2 TY + 2) x (2 XT + 2) big pixels][PB]: 32 channels
+    char* sl = smem + BPX * PB;                   // [TY x XT small pixels][PS]: 64 channels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave & 1, kyp = wave >> 1;
+    const int cs0 = blockIdx.x * 64, cb0 = blockIdx.y * 32;
+    const int oh = a.h >> 1, ow = a.w >> 1;
+    const long long u_begin = (long long)blockIdx.z * a.per;
+    const long long u_end = u_begin + a.per < a.units ? u_begin + a.per : a.units;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 bv[BN], sv[SN];
+    auto load = [&](long long u) {
+        const int yt = (int)(u % a.ytiles);
+        const long long t = u / a.ytiles;
+        const int strip = (int)(t % a.strips);
+        const long long frame = t / a.strips;
+        const int x0 = strip * XT, y0 = yt * TY;
+        const __bf16* bb = a.big + frame * a.h * a.w * a.ldb + cb0 + (tid & 3) * 8;
+        const __bf16* sb = a.small + frame * oh * ow * a.lds + cs0 + (tid & 7) * 8;
+        const bool b_ok = cb0 + (tid & 3) * 8 < a.cb, s_ok = cs0 + (tid & 7) * 8 < a.cs;
+#pragma unroll
+        for (int k = 0; k < BN; ++k) {
+            const int p = (tid >> 2) + 64 * k, hy = p / HXB, hx = p % HXB;
+            const int gy = 2 * y0 - 1 + hy, gx = 2 * x0 - 1 + hx;
+            const bool ok = b_ok && p < BPX && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+            bv[k] = ok ? *reinterpret_cast<const bf16x8*>(bb + ((long long)gy * a.w + gx) * a.ldb) : zero8;
+        }
+#pragma unroll
+        for (int k = 0; k < SN; ++k) {
+            const int p = (tid >> 3) + 32 * k, ty = p / XT, tx = p % XT;
+            const int gy = y0 + ty, gx = x0 + tx;
+            const bool ok = s_ok && gy < oh && gx < ow;
+            sv[k] = ok ? *reinterpret_cast<const bf16x8*>(sb + ((long long)gy * ow + gx) * a.lds) : zero8;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int k = 0; k < BN; ++k) {
+            const int p = (tid >> 2) + 64 * k;
+            if (p < BPX) *reinterpret_cast<bf16x8*>(bl + p * PB + (tid & 3) * 16) = bv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < SN; ++k) *reinterpret_cast<bf16x8*>(sl + ((tid >> 3) + 32 * k) * PS + (tid & 7) * 16) = sv[k];
+    };
+    // fragment addresses: an LDS row is a pixel; the small operand's contraction step is 16 consecutive rows, the big
+    // operand's 16 rows two apart
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int frag_row = 8 * (g >> 1) + q, frag_col = 16 * (g & 1) + 4 * pp;
+    const char* fa = sl + frag_row * PS + (wm * 32 + frag_col) * 2;
+    const char* fb = bl + 2 * frag_row * PB + frag_col * 2;
+    typedef __attribute__((address_space(3))) s4v* lds_s4;
+    auto big_fragment = [&](const char* base) -> bf16x8 {
+        const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base));
+        const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base + 8 * PB));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 acc[8];                                // [ky in {kyp, kyp + 2}][kx]
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (u_begin < u_end) {
+        load(u_begin);
+        for (long long u = u_begin; u < u_end; ++u) {
+            store();
+            __syncthreads();
+            if (u + 1 < u_end) load(u + 1);        // in flight during this tile's products
+            bf16x8 c[2][4];
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) c[0][kx] = big_fragment(fb + (kyp * HXB + kx) * PB);
+#pragma unroll
+            for (int ty = 0; ty < TY; ++ty) {
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) c[1][kx] = big_fragment(fb + ((2 * ty + kyp + 2) * HXB + kx) * PB);
+                const bf16x8 A = lds_tr_fragment(fa + ty * XT * PS);
+#pragma unroll
+                for (int kl = 0; kl < 2; ++kl)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx)
+                        acc[4 * kl + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, c[kl][kx], acc[4 * kl + kx], 0, 0, 0);
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) c[0][kx] = c[1][kx];
+            }
+            __syncthreads();                       // the next tile overwrites both buffers
+        }
+    }
+    float* part = a.part + ((size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * (16 * 2048);
+#pragma unroll
+    for (int kl = 0; kl < 2; ++kl)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                part[(((kyp + 2 * kl) * 4 + kx) * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[4 * kl + kx][r];
+}
+
+// dw[cs][cb][16] = sum over the nz partial sets of part[z][tile (cb tile slow)][tap][64][32], in order
+__global__ __launch_bounds__(256) void wgrad4_reduce_kernel(const float* __restrict__ part, int nz, int tx, int ty,
+                                                            float* __restrict__ dw, int cs, int cb) {
+    const size_t per_z = (size_t)tx * ty * 16 * 2048;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= per_z) return;
+    const int c = (int)(e & 31), r = (int)((e >> 5) & 63), t = (int)((e >> 11) & 15);
+    const int tile = (int)(e >> 15), txi = tile % tx, tyi = tile / tx;
+    const int co = txi * 64 + r, ci = tyi * 32 + c;
+    if (co >= cs || ci >= cb) return;
+    float sum = 0.f;
+#pragma unroll 8
+    for (int z = 0; z < nz; ++z) sum += part[(size_t)z * per_z + e];
+    dw[((size_t)co * cb + ci) * 16 + t] = sum;
+}
+
 // The same product with a 128 x 128 tile per workgroup (eight waves: 2 x 2 blocks of 64 x 64 output channels, times two
 // halves of a stage's 64 rows).  A 64 x 64 tile makes the launch read the rows of x once per 64 output channels and the
 // rows of dy once per 64 input channels through L2 - three to six times the operands' size on the layers of a training
@@ -1237,6 +1381,56 @@ extern "C" int vdmi_conv_wgrad_rows(const void* x, int ldx, const void* dy, int 
     const long long elems = (long long)p.tx * p.ty * 9 * 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, a.part, (int)p.gz, p.tx,
                        p.ty, 9, dw, cout, cin, cin_total, cin_off);
+    VDMI_LAUNCH_CHECK();
+    return VDMI_OK;
+}
+
+namespace {
+struct Wgrad4Plan { int tx, ty, strips, ytiles; long long units, per, gz; };
+int wgrad4_plan(int cb, int cs, int nf, int h, int w, Wgrad4Plan* p) {
+    if (cb <= 0 || cs <= 0 || cb % 8 || cs % 8 || nf <= 0 || h <= 0 || w <= 0 || h % 2 || w % 2) return VDMI_E_SHAPE;
+    if ((long long)nf * h * w > 0x7fffffffLL) return VDMI_E_SHAPE;
+    p->tx = (cs + 63) / 64;
+    p->ty = (cb + 31) / 32;
+    if (p->tx > 65535 || p->ty > 65535) return VDMI_E_SHAPE;
+    p->strips = (w / 2 + W4_XT - 1) / W4_XT;
+    p->ytiles = (h / 2 + W4_TY - 1) / W4_TY;
+    p->units = (long long)nf * p->strips * p->ytiles;
+    long long split = 512 / ((long long)p->tx * p->ty);      // 63 KiB of LDS: two workgroups per CU, one round
+    if (split > p->units) split = p->units;
+    if (split < 1) split = 1;
+    p->per = (p->units + split - 1) / split;
+    p->gz = (p->units + p->per - 1) / p->per;
+    return p->gz > 65535 ? VDMI_E_SHAPE : VDMI_OK;
+}
+}   // namespace
+
+extern "C" size_t vdmi_strided_wgrad_rows_workspace_bytes(int cb, int cs, int nf, int h, int w) {
+    Wgrad4Plan p;
+    if (wgrad4_plan(cb, cs, nf, h, w, &p) != VDMI_OK) return 0;
+    return (size_t)p.gz * p.tx * p.ty * 16 * 2048 * sizeof(float);
+}
+
+extern "C" int vdmi_strided_wgrad_rows(const void* big, int ldb, const void* small, int lds, float* dw, int cb, int cs,
+                                       int nf, int h, int w, void* workspace, vdmi_stream stream) {
+    if (!big || !small || !dw || !workspace) return VDMI_E_ARG;
+    if (ldb < cb || lds < cs || ldb % 8 || lds % 8) return VDMI_E_SHAPE;
+    Wgrad4Plan p;
+    const int st = wgrad4_plan(cb, cs, nf, h, w, &p);
+    if (st != VDMI_OK) return st;
+    if (!aligned16(big) || !aligned16(small) || !aligned16(workspace)) return VDMI_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Wgrad4Args a;
+    a.big = static_cast<const __bf16*>(big);
+    a.small = static_cast<const __bf16*>(small);
+    a.part = static_cast<float*>(workspace);
+    a.ldb = ldb; a.lds = lds; a.cb = cb; a.cs = cs; a.h = h; a.w = w;
+    a.strips = p.strips; a.ytiles = p.ytiles; a.units = p.units; a.per = p.per;
+    hipLaunchKernelGGL(wgrad4x4s2_rows_kernel, dim3((unsigned)p.tx, (unsigned)p.ty, (unsigned)p.gz), dim3(256), W4_LDS, s, a);
+    VDMI_LAUNCH_CHECK();
+    const long long elems = (long long)p.tx * p.ty * 16 * 2048;
+    hipLaunchKernelGGL(wgrad4_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, a.part, (int)p.gz, p.tx,
+                       p.ty, dw, cs, cb);
     VDMI_LAUNCH_CHECK();
     return VDMI_OK;
 }

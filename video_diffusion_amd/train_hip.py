@@ -1146,6 +1146,11 @@ def up_conv_rows(x: torch.Tensor, weight: torch.Tensor, bias, frames: int, fpb: 
     return out
 
 
+# VDMI_STRIDED_WGRAD=0: the resampling convolutions' weight gradient as four one-tap gradients over a padded
+# space-to-depth copy (A/B switch)
+_STRIDED_WGRAD_ROWS = os.environ.get("VDMI_STRIDED_WGRAD", "1") != "0"
+
+
 def strided_wgrad(big: torch.Tensor, small: torch.Tensor, frames: int, h: int, w: int) -> torch.Tensor:
     """dW[cs][cb][ky][kx] = sum over frames and small-image pixels q of small[q][cs] * big[2q + (ky-1, kx-1)][cb]: the
     weight gradient of the (1,4,4) / stride 2 / pad 1 convolution from big (h x w) to small (h/2 x w/2), and - with the
@@ -1153,6 +1158,17 @@ def strided_wgrad(big: torch.Tensor, small: torch.Tensor, frames: int, h: int, w
     space-to-depth view of `big`."""
     cb, cs = big.shape[1], small.shape[1]
     oh, ow = h // 2, w // 2
+    if _STRIDED_WGRAD_ROWS:
+        # one launch over the rows as they lie (+ the partial-tile reduce); below: the same sum as four one-tap gradients
+        # over a padded space-to-depth copy of `big`
+        assert big.shape[0] == frames * h * w and small.shape[0] == frames * oh * ow
+        assert big.is_contiguous() and small.is_contiguous()
+        lib = _lib.lib()
+        dw = torch.empty(cs, cb, 1, 4, 4, device=big.device, dtype=torch.float32)
+        ws = torch.empty(lib.vdmi_strided_wgrad_rows_workspace_bytes(cb, cs, frames, h, w), device=big.device, dtype=torch.uint8)
+        check(lib.vdmi_strided_wgrad_rows(big.data_ptr(), cb, small.data_ptr(), cs, dw.data_ptr(), cb, cs, frames, h, w,
+                                          ws.data_ptr(), _stream()), "vdmi_strided_wgrad_rows")
+        return dw
     bp = F.pad(big.view(frames, h, w, cb), (0, 0, 1, 1, 1, 1))                      # zero border of one pixel
     s2d = bp.view(frames, oh + 1, 2, ow + 1, 2, cb).permute(0, 1, 3, 2, 4, 5).reshape(frames * (oh + 1) * (ow + 1), 4 * cb)
     sp = F.pad(small.view(frames, oh, ow, cs), (0, 0, 0, 1, 0, 1)).reshape(frames * (oh + 1) * (ow + 1), cs)
